@@ -1,0 +1,111 @@
+"""ctypes binding of libdcv.so (include/dcv.h).  Fails loudly when the library is absent."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdcv.so")
+
+DCV_MAX_LAYERS = 16
+ACT = {None: 0, "linear": 0, "leaky_relu": 1, "relu": 2, "tanh": 3, "elu": 4, "softplus": 5}
+MODEL_DEEPTICA = 1
+MODEL_AE = 2
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("dims", C.c_int32 * (DCV_MAX_LAYERS + 1)),
+        ("act", C.c_int32 * DCV_MAX_LAYERS),
+        ("latent_layer", C.c_int32),
+        ("lag", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("tica_reg", C.c_double),
+        ("lr", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+        ("eps", C.c_double),
+        ("weight_decay", C.c_double),
+    ]
+
+
+class DcvError(RuntimeError):
+    pass
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I32 = C.c_int32
+_SZ = C.c_size_t
+
+# name -> (restype, argtypes); every symbol declared in include/dcv.h
+SIGNATURES = {
+    "dcv_abi_version": (C.c_int, []),
+    "dcv_last_error": (C.c_char_p, []),
+    "dcv_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(_I64), C.c_char_p, _SZ]),
+    "dcv_col_stats_workspace": (_SZ, [_I64, _I32]),
+    "dcv_col_stats": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _SZ, _P]),
+    "dcv_normalize": (C.c_int, [_P, _P, _I64, _I32, _I64, _I64, _P, _P, _P]),
+    "dcv_lagged_cov_workspace": (_SZ, [_I64, _I32, _I32]),
+    "dcv_lagged_cov": (C.c_int, [_P, _I64, _I32, _I64, _I32, _P, _P, _P, _SZ, _P]),
+    "dcv_project_linear_workspace": (_SZ, [_I64, _I32, _I32]),
+    "dcv_project_linear": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P, _SZ, _P]),
+    "dcv_mlp_create": (C.c_int, [C.POINTER(MlpDesc), C.POINTER(_P)]),
+    "dcv_mlp_destroy": (None, [_P]),
+    "dcv_mlp_num_params": (_I64, [_P]),
+    "dcv_mlp_param_offset": (_I64, [_P, _I32, _I32]),
+    "dcv_mlp_params": (_P, [_P]),
+    "dcv_mlp_grads": (_P, [_P]),
+    "dcv_mlp_set_params": (C.c_int, [_P, _P, _P]),
+    "dcv_mlp_get_params": (C.c_int, [_P, _P, _P]),
+    "dcv_mlp_set_lr": (C.c_int, [_P, C.c_double]),
+    "dcv_mlp_set_feature_range": (C.c_int, [_P, _P, _P]),
+    "dcv_mlp_forward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
+    "dcv_mlp_stats": (_P, [_P]),
+    "dcv_mlp_stats_len": (_I32, [_P]),
+    "dcv_mlp_backward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I64, _I32, _P]),
+    "dcv_mlp_apply": (C.c_int, [_P, _P]),
+    "dcv_mlp_train_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
+    "dcv_mlp_eval_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
+    "dcv_mlp_log_width": (_I32, [_P]),
+    "dcv_mlp_reset_log": (C.c_int, [_P, _I32, _P]),
+    "dcv_mlp_read_log": (C.c_int, [_P, _P, _I32, C.POINTER(_I32), _P]),
+    "dcv_mlp_infer": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "dcv_kmeans_workspace": (_SZ, [_I64, _I32, _I32]),
+    "dcv_kmeans_step": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "dcv_nearest_rows_workspace": (_SZ, [_I64, _I32, _I32]),
+    "dcv_nearest_rows": (C.c_int, [_P, _I64, _I32, _P, _I32, _I64, _P, _P, _P, _SZ, _P]),
+    "dcv_nearest_point": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _P]),
+    "dcv_gemm_f32": (C.c_int, [_I32, _P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libdcv.so and bind every entry point.  Raises DcvError if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DcvError(
+            f"libdcv.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C deep_cartograph_amd/csrc` -- there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    ver = lib.dcv_abi_version()
+    if ver != 1:
+        raise DcvError(f"libdcv.so ABI version {ver}, expected 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().dcv_last_error().decode(errors="replace")
+        raise DcvError(f"{what} failed (code {rc}): {msg}")

@@ -1,0 +1,41 @@
+// Shared helpers for libdcv.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/dcv.h"
+
+namespace dcv {
+
+void set_error(const char* fmt, ...);
+
+#define DCV_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            dcv::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return DCV_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+
+#define DCV_REQUIRE(cond, ...)                                                           \
+    do {                                                                                 \
+        if (!(cond)) {                                                                   \
+            dcv::set_error(__VA_ARGS__);                                                 \
+            return DCV_EINVAL;                                                           \
+        }                                                                                \
+    } while (0)
+
+#define DCV_CHECK_LAUNCH() DCV_CHECK_HIP(hipGetLastError())
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;  // gfx950 wavefront
+
+// Number of CUs of the current device (cached).
+int num_cus();
+
+}  // namespace dcv

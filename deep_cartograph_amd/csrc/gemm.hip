@@ -1,0 +1,21 @@
+// Plain C = op(A) . op(B) entry point over the FP32 MFMA engine (building block, used by the
+// parity tests to check every operand form and tile shape against a float64 product).
+#include <type_traits>
+#include "gemm_kernels.h"
+
+using namespace dcv;
+
+extern "C" int dcv_gemm_f32(int32_t mode, const float* A_d, int64_t lda, const float* B_d, int64_t ldb, float* C_d,
+                            int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream) {
+    DCV_REQUIRE(A_d && B_d && C_d && M > 0 && N > 0 && K > 0, "dcv_gemm_f32: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const Operand A = make_operand(A_d, lda, 0);
+    const Operand B = make_operand(B_d, ldb, 0);
+    EpiStore epi{C_d, ldc};
+    switch (mode) {
+        case kNT: return launch_gemm<kNT, EpiStore>(A, B, M, N, K, 0, epi, s);
+        case kNN: return launch_gemm<kNN, EpiStore>(A, B, M, N, K, 0, epi, s);
+        case kTN: return launch_gemm<kTN, EpiStore>(A, B, M, N, K, 0, epi, s);  // single split
+        default: set_error("dcv_gemm_f32: mode %d", mode); return DCV_EINVAL;
+    }
+}

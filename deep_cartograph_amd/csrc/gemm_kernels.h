@@ -1,0 +1,138 @@
+// __global__ wrappers, epilogues and launch helpers around the block-tile engine of gemm.h.
+#pragma once
+#include <type_traits>
+#include "gemm.h"
+
+namespace dcv {
+
+// ------------------------------------------------------------------ activations
+__device__ __forceinline__ float act_fwd(int act, float z) {
+    switch (act) {
+        case DCV_ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
+        case DCV_ACT_RELU: return z > 0.f ? z : 0.f;
+        case DCV_ACT_TANH: return tanhf(z);
+        case DCV_ACT_ELU: return z > 0.f ? z : expm1f(z);
+        case DCV_ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
+        default: return z;
+    }
+}
+// derivative expressed through the stored post-activation value h = act(z)
+__device__ __forceinline__ float act_grad_from_out(int act, float h) {
+    switch (act) {
+        case DCV_ACT_LEAKY_RELU: return h > 0.f ? 1.f : 0.01f;
+        case DCV_ACT_RELU: return h > 0.f ? 1.f : 0.f;
+        case DCV_ACT_TANH: return 1.f - h * h;
+        case DCV_ACT_ELU: return h > 0.f ? 1.f : h + 1.f;
+        case DCV_ACT_SOFTPLUS: return h > 20.f ? 1.f : 1.f - expf(-h);
+        default: return 1.f;
+    }
+}
+
+// ------------------------------------------------------------------ epilogues
+struct EpiStore {  // C = acc
+    float* C;
+    int64_t ldc;
+    __device__ __forceinline__ void operator()(int, int64_t r, int64_t c, float v) const { C[r * ldc + c] = v; }
+};
+struct EpiBiasAct {  // H = act(acc + bias[col])
+    float* C;
+    int64_t ldc;
+    const float* bias;
+    int act;
+    __device__ __forceinline__ void operator()(int, int64_t r, int64_t c, float v) const {
+        C[r * ldc + c] = act_fwd(act, v + (bias ? bias[c] : 0.f));
+    }
+};
+struct EpiActGrad {  // dZ = acc * act'(H)
+    float* C;
+    int64_t ldc;
+    const float* H;
+    int64_t ldh;
+    int act;
+    __device__ __forceinline__ void operator()(int, int64_t r, int64_t c, float v) const {
+        C[r * ldc + c] = v * act_grad_from_out(act, H[r * ldh + c]);
+    }
+};
+struct EpiSlab {  // split-K partials: slab[z][which][M][N]
+    float* slab;
+    int64_t M, N;
+    int nb;
+    int64_t z;
+    __device__ __forceinline__ void operator()(int which, int64_t r, int64_t c, float v) const {
+        slab[((z * nb + which) * M + r) * N + c] = v;
+    }
+};
+
+// ------------------------------------------------------------------ kernels
+// grid.x = tiles_m * tiles_n (tile_n fastest), grid.z = k splits (TN only)
+template <int MODE, class Cfg, int NB, class Epi>
+__global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int tile = blockIdx.x;
+    const int tile_m = tile / d.tiles_n;
+    const int tile_n = tile - tile_m * d.tiles_n;
+    int64_t k_begin = 0, k_end = d.K;
+    if constexpr (MODE == kTN) {
+        k_begin = (int64_t)blockIdx.z * d.k_chunk;
+        k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
+        if constexpr (std::is_same<Epi, EpiSlab>::value) epi.z = blockIdx.z;
+    }
+    gemm_block<MODE, Cfg, NB, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
+}
+
+using CfgBig = TileCfg<2, 2, 2, 2, 32>;      // 128 x 128
+using CfgNarrowN = TileCfg<4, 1, 1, 1, 32>;  // 128 x 32
+using CfgNarrowM = TileCfg<1, 4, 1, 1, 32>;  // 32 x 128
+using CfgCov = TileCfg<2, 2, 2, 2, 16>;      // 128 x 128, two B operands, 48 KiB LDS
+
+template <int MODE, class Cfg, int NB, class Epi>
+static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int64_t M, int64_t N, int64_t K,
+                           int64_t k_chunk, const Epi& epi, hipStream_t s) {
+    GemmDims d;
+    d.M = M;
+    d.N = N;
+    d.K = K;
+    d.k_chunk = k_chunk > 0 ? k_chunk : K;
+    d.tiles_m = (int)cdiv(M, Cfg::TM);
+    d.tiles_n = (int)cdiv(N, Cfg::TN);
+    const int64_t splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
+    const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
+    DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
+                (long long)tiles, (long long)splits);
+    constexpr size_t lds = gemm_lds_bytes<Cfg, NB>();
+    auto kern = gemm_kernel<MODE, Cfg, NB, Epi>;
+    if (lds > 64 * 1024) {
+        static bool attr_set = false;  // per instantiation
+        if (!attr_set) {
+            DCV_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+// Picks the tile shape from the output extents.
+template <int MODE, class Epi>
+static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
+                       const Epi& epi, hipStream_t s) {
+    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowN, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s);
+    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s);
+    return launch_gemm_cfg<MODE, CfgBig, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s);
+}
+
+inline Operand make_operand(const float* p, int64_t ld, int64_t inner_extent, const RowMap& rows = RowMap{nullptr, 0, 0, 0},
+                            const float* shift = nullptr) {
+    Operand o;
+    o.p = p;
+    o.ld = ld;
+    o.rows = rows;
+    o.shift = shift;
+    (void)inner_extent;
+    o.vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0) &&
+               (shift == nullptr || (reinterpret_cast<uintptr_t>(shift) & 15) == 0);
+    return o;
+}
+
+}  // namespace dcv

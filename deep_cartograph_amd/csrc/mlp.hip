@@ -1,0 +1,778 @@
+// MLP engine: Deep-TICA and autoencoder training / inference on the FP32 MFMA block engine.
+//
+// A step never materialises the batch: the first layer gathers its rows straight from the
+// resident, pre-normalised feature matrix through a RowMap (x_t rows, then the same samples
+// `lag` rows later for Deep-TICA).  Every Linear layer is three products on the same engine
+//   forward  H_l  = act(In_l W_l^T + b_l)                      NT, fused bias + activation
+//   dgrad    dZ_{l-1} = (dZ_l W_l) * act'(H_{l-1})             NN, fused activation gradient
+//   wgrad    dW_l = dZ_l^T In_l                                TN, split over the batch rows
+// wgrad split partials and the bias column sums are folded in a fixed order by one reduction
+// kernel (deterministic), Adam is one more launch.  The d x d TICA algebra of the Deep-TICA
+// loss runs in float64 on the device from batch statistics that a data-parallel caller
+// all-reduces, so nothing returns to the host inside an epoch.
+#include "gemm_kernels.h"
+#include <vector>
+#include <new>
+#include <math.h>
+
+namespace dcv {
+
+constexpr int kMaxTicaDim = 16;
+
+struct LayerPlan {
+    int in, out, act;
+    int64_t w_off, b_off;      // offsets into the flat parameter buffer (floats, 16-byte aligned)
+    int64_t ldh;               // row stride of the activation buffer
+    float* H;                  // [rows][ldh] post-activation output
+    // wgrad split-K
+    int64_t k_chunk_cap;       // rows per split at full capacity
+    int64_t max_splits;
+    float* slab;               // [max_splits][out][in]
+    float* bpart;              // [bias_blocks_cap][out]
+};
+
+}  // namespace dcv
+
+using namespace dcv;
+
+struct dcv_mlp {
+    dcv_mlp_desc desc;
+    int L;
+    int d_out;                 // dims[L]
+    int64_t rows_cap;          // rows per step at max_batch
+    int64_t n_params;
+    std::vector<LayerPlan> layers;
+    float *params, *grads, *adam_m, *adam_v;
+    float* dZ[2];
+    int64_t ld_dz;
+    double* stats;             // device
+    int stats_len;
+    float* gradp;              // Deep-TICA: [mu d | Gu d*d | Gv d*d | c d]
+    double* spart;             // stats partials
+    int spart_blocks;
+    double* log;
+    int* log_count;
+    int log_cap, log_width;
+    float* feat_range;         // AE
+    float *ident, *zeros_d, *ones_d;  // helpers for inference
+    float* proj_ws;
+    size_t proj_ws_bytes;
+    int64_t adam_t;
+    double lr;
+    // bookkeeping of the last forward (backward must match)
+    int32_t last_batch;
+};
+
+namespace dcv {
+
+constexpr int kColsumRows = 128;
+constexpr int kStatBlockRows = 128;
+
+// ------------------------------------------------------------------ small kernels
+// partial column sums of dZ (rows x n): part[block][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Z, int64_t rows, int n, int64_t ld,
+                                                     float* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
+    const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
+    for (int c = threadIdx.x; c < n; c += 256) {
+        float s = 0.f;
+        for (int64_t r = r0; r < r1; ++r) s += Z[r * ld + c];
+        part[(int64_t)blockIdx.x * n + c] = s;
+    }
+}
+
+struct ReduceDesc {
+    const float* slab;   // [splits][count]
+    const float* bpart;  // [bblocks][out]
+    int64_t w_off, b_off;
+    int64_t w_count;     // out*in
+    int out;
+    int splits, bblocks;
+};
+struct ReduceArgs {
+    ReduceDesc l[DCV_MAX_LAYERS];
+    int L;
+};
+
+// grads[w] = sum_s slab[s][w] ; grads[b] = sum_blk bpart[blk][b].  A block covers 64 consecutive
+// elements; its 4 waves take the partials q = wave, wave + 4, ... (coalesced 256-byte reads) and
+// are combined in wave order: float64 accumulation, fixed order, deterministic.
+__global__ __launch_bounds__(256) void reduce_grads_kernel(ReduceArgs a, float* __restrict__ grads, float scale) {
+    __shared__ double s_red[4][64];
+    const int l = blockIdx.y;
+    const ReduceDesc& d = a.l[l];
+    const int64_t total = d.w_count + d.out;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
+        double s = 0.0;
+        if (i < d.w_count) {
+            for (int q = wave; q < d.splits; q += 4) s += (double)d.slab[(int64_t)q * d.w_count + i];
+        } else if (i < total) {
+            const int64_t j = i - d.w_count;
+            for (int q = wave; q < d.bblocks; q += 4) s += (double)d.bpart[(int64_t)q * d.out + j];
+        }
+        s_red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && i < total) {
+            const double tot = ((s_red[0][lane] + s_red[1][lane]) + s_red[2][lane]) + s_red[3][lane];
+            const float g = (float)(tot * (double)scale);
+            if (i < d.w_count) grads[d.w_off + i] = g;
+            else grads[d.b_off + (i - d.w_count)] = g;
+        }
+        __syncthreads();
+    }
+}
+
+// torch.optim.Adam (single-tensor form), fp32 state
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr_over_bc1, float bc2_sqrt,
+                                                   float beta1, float beta2, float eps, float wd) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float gi = g[i];
+        const float pi = p[i];
+        if (wd != 0.f) gi = fmaf(wd, pi, gi);
+        float mi = m[i], vi = v[i];
+        mi = mi + (gi - mi) * (1.f - beta1);           // exp_avg.lerp_(grad, 1 - beta1)
+        vi = vi * beta2 + (1.f - beta2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = pi - lr_over_bc1 * (mi / denom);
+    }
+}
+
+// ------------------------------------------------------------------ Deep-TICA batch statistics
+// F: rows [0,B) = f_t, rows [B,2B) = f_lag, d columns.  Each block stages kStatBlockRows pairs in
+// LDS (float64) and every thread owns whole outputs of [sum f_t | sum f_lag | sum f_t f_t^T |
+// sum f_t f_lag^T]; part[block][2d + 2d^2] float64, combined in block order afterwards.
+__global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict__ F, int64_t ld, int B, int d,
+                                                         double* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_t = reinterpret_cast<double*>(smem);   // [rows][d]
+    double* s_l = s_t + kStatBlockRows * d;           // [rows][d]
+    const int W = 2 * d + 2 * d * d;
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * kStatBlockRows;
+    const int nr = (int)(r0 + kStatBlockRows < B ? kStatBlockRows : B - r0);
+    for (int i = t; i < nr * d; i += 256) {
+        const int r = i / d, c = i - r * d;
+        s_t[i] = (double)F[(r0 + r) * ld + c];
+        s_l[i] = (double)F[(r0 + r + B) * ld + c];
+    }
+    __syncthreads();
+    double* my = part + (int64_t)blockIdx.x * W;
+    for (int o = t; o < W; o += 256) {
+        double s = 0.0;
+        if (o < d) {
+            for (int r = 0; r < nr; ++r) s += s_t[r * d + o];
+        } else if (o < 2 * d) {
+            for (int r = 0; r < nr; ++r) s += s_l[r * d + o - d];
+        } else if (o < 2 * d + d * d) {
+            const int q = o - 2 * d, i = q / d, j = q % d;
+            for (int r = 0; r < nr; ++r) s += s_t[r * d + i] * s_t[r * d + j];
+        } else {
+            const int q = o - 2 * d - d * d, i = q / d, j = q % d;
+            for (int r = 0; r < nr; ++r) s += s_t[r * d + i] * s_l[r * d + j];
+        }
+        my[o] = s;
+    }
+}
+
+// out[i] = sum_b part[b][i], one wave per output, fixed combination tree
+__global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ part, int nblocks, int width,
+                                                          double* __restrict__ out) {
+    const int i = blockIdx.x;
+    if (i >= width) return;
+    const int lane = threadIdx.x;
+    double s = 0.0;
+    for (int b = lane; b < nblocks; b += 64) s += part[(int64_t)b * width + i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (lane == 0) out[i] = s;
+}
+
+// One thread: C0, Ctau, loss = -tr((A Ctau)^2) with A = (C0 + reg I)^-1, and the matrices that
+// turn (f_t - mu, f_lag - mu) into dL/df (see DESIGN.md "Deep-TICA gradient").
+__global__ void tica_grad_kernel(const double* __restrict__ stats, int d, double Bg, double reg, float* __restrict__ gradp,
+                                 double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double mu[kMaxTicaDim], ml[kMaxTicaDim];
+    double C0[kMaxTicaDim * kMaxTicaDim], Ct[kMaxTicaDim * kMaxTicaDim], A[kMaxTicaDim * kMaxTicaDim];
+    double K[kMaxTicaDim * kMaxTicaDim], T[kMaxTicaDim * kMaxTicaDim], Lc[kMaxTicaDim * kMaxTicaDim];
+    const double* sft = stats;
+    const double* sfl = stats + d;
+    const double* Stt = stats + 2 * d;
+    const double* Stl = stats + 2 * d + d * d;
+    for (int i = 0; i < d; ++i) {
+        mu[i] = sft[i] / Bg;
+        ml[i] = sfl[i] / Bg;
+    }
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            C0[i * d + j] = 0.5 * (Stt[i * d + j] + Stt[j * d + i]) / Bg - mu[i] * mu[j];
+            const double cij = Stl[i * d + j] / Bg - mu[i] * ml[j];
+            const double cji = Stl[j * d + i] / Bg - mu[j] * ml[i];
+            Ct[i * d + j] = 0.5 * (cij + cji);
+        }
+    // Cholesky of C0 + reg I
+    bool ok = true;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = C0[i * d + j] + (i == j ? reg : 0.0);
+            for (int k = 0; k < j; ++k) s -= Lc[i * d + k] * Lc[j * d + k];
+            if (i == j) {
+                if (!(s > 0.0)) ok = false;
+                Lc[i * d + i] = sqrt(s);
+            } else {
+                Lc[i * d + j] = s / Lc[j * d + j];
+            }
+        }
+    // A = (L L^T)^-1 : solve L Y = I, then L^T A = Y
+    for (int c = 0; c < d; ++c) {
+        double y[kMaxTicaDim];
+        for (int i = 0; i < d; ++i) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int k = 0; k < i; ++k) s -= Lc[i * d + k] * y[k];
+            y[i] = s / Lc[i * d + i];
+        }
+        for (int i = d - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int k = i + 1; k < d; ++k) s -= Lc[k * d + i] * A[k * d + c];
+            A[i * d + c] = s / Lc[i * d + i];
+        }
+    }
+    // K = A Ct ; loss = -tr(K K)
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += A[i * d + k] * Ct[k * d + j];
+            K[i * d + j] = s;
+        }
+    double loss = 0.0;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) loss -= K[i * d + j] * K[j * d + i];
+    if (!ok) loss = NAN;
+    if (gradp) {
+        // T = K A  (= A Ct A, symmetric) ; Gtau = -2 T ; G0 = 2 K T
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s += K[i * d + k] * A[k * d + j];
+                T[i * d + j] = s;
+            }
+        float* g_mu = gradp;
+        float* g_u = gradp + d;
+        float* g_v = g_u + d * d;
+        float* g_c = g_v + d * d;
+        for (int i = 0; i < d; ++i) g_mu[i] = (float)mu[i];
+        for (int i = 0; i < d; ++i) {
+            double cs = 0.0;
+            for (int j = 0; j < d; ++j) {
+                double g0 = 0.0;
+                for (int k = 0; k < d; ++k) g0 += K[i * d + k] * T[k * d + j];
+                const double Gt = -2.0 * 0.5 * (T[i * d + j] + T[j * d + i]);
+                g_u[i * d + j] = (float)(2.0 * (2.0 * g0) / Bg);  // (2/B) G0, G0 = 2 K T
+                g_v[i * d + j] = (float)(Gt / Bg);                // (1/B) Gtau
+                cs += Gt * (ml[j] - mu[j]);
+            }
+            g_c[i] = (float)(-cs / Bg);
+        }
+    }
+    const int slot = *log_count;
+    if (slot < log_cap) {
+        double* rec = log + (int64_t)slot * log_width;
+        rec[0] = loss;
+        rec[1] = Bg;
+        for (int i = 0; i < d * d; ++i) rec[2 + i] = C0[i];
+        for (int i = 0; i < d * d; ++i) rec[2 + d * d + i] = Ct[i];
+        for (int i = 0; i < d; ++i) rec[2 + 2 * d * d + i] = mu[i];
+    }
+    *log_count = slot + 1;
+}
+
+// dZ_last rows: t rows get Gu u + Gv v + c, lag rows get Gv u  (then * act'(F) of the last layer)
+__global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ F, int64_t ldf, int B, int d,
+                                                      const float* __restrict__ gradp, int act, float* __restrict__ dZ,
+                                                      int64_t ldz) {
+    __shared__ float s_g[kMaxTicaDim * (2 * kMaxTicaDim + 2)];
+    const int np = d + 2 * d * d + d;
+    for (int i = threadIdx.x; i < np; i += 256) s_g[i] = gradp[i];
+    __syncthreads();
+    const float* mu = s_g;
+    const float* Gu = s_g + d;
+    const float* Gv = Gu + d * d;
+    const float* cv = Gv + d * d;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= B) return;
+    float u[kMaxTicaDim], v[kMaxTicaDim];
+    const float* ft = F + r * ldf;
+    const float* fl = F + (r + B) * ldf;
+    for (int i = 0; i < d; ++i) {
+        u[i] = ft[i] - mu[i];
+        v[i] = fl[i] - mu[i];
+    }
+    for (int i = 0; i < d; ++i) {
+        float gt = cv[i], gl = 0.f;
+        for (int j = 0; j < d; ++j) {
+            gt = fmaf(Gu[i * d + j], u[j], gt);
+            gt = fmaf(Gv[i * d + j], v[j], gt);
+            gl = fmaf(Gv[i * d + j], u[j], gl);
+        }
+        dZ[r * ldz + i] = gt * act_grad_from_out(act, ft[i]);
+        dZ[(r + B) * ldz + i] = gl * act_grad_from_out(act, fl[i]);
+    }
+}
+
+// ------------------------------------------------------------------ autoencoder loss
+// SSE = sum ((y - xn) * range)^2 over rows x F ; part[block]
+__global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Xn,
+                                                     int64_t ldx, RowMap rows, int64_t R, int F,
+                                                     const float* __restrict__ range, double* __restrict__ part) {
+    __shared__ double red[256];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int64_t r1 = r0 + 64 < R ? r0 + 64 : R;
+    double s = 0.0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float* y = Y + r * ldy;
+        const float* x = Xn + rows(r) * ldx;
+        for (int c = t; c < F; c += 256) {
+            const float e = (y[c] - x[c]) * range[c];
+            s += (double)e * (double)e;
+        }
+    }
+    red[t] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    if (t == 0) part[blockIdx.x] = red[0];
+}
+
+// dY = scale * (y - xn) * range^2 * act'(y)
+__global__ __launch_bounds__(256) void ae_dY_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Xn,
+                                                    int64_t ldx, RowMap rows, int64_t R, int F,
+                                                    const float* __restrict__ range, float scale, int act,
+                                                    float* __restrict__ dZ, int64_t ldz) {
+    const int64_t total = R * F;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / F;
+        const int c = (int)(i - r * F);
+        const float y = Y[r * ldy + c];
+        const float x = Xn[rows(r) * ldx + c];
+        const float rg = range[c];
+        dZ[r * ldz + c] = scale * (y - x) * rg * rg * act_grad_from_out(act, y);
+    }
+}
+
+__global__ void ae_log_kernel(const double* __restrict__ stats, double Bg, int F, double* __restrict__ log,
+                              int* __restrict__ log_count, int log_cap, int log_width) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int slot = *log_count;
+    if (slot < log_cap) {
+        log[(int64_t)slot * log_width + 0] = stats[0] / (Bg * (double)F);
+        log[(int64_t)slot * log_width + 1] = Bg;
+    }
+    *log_count = slot + 1;
+}
+
+__global__ void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+
+static RowMap batch_rows(const dcv_mlp* m, const int64_t* idx, int64_t row0, int batch) {
+    if (m->desc.model == DCV_MODEL_DEEPTICA) return RowMap{idx, row0, batch, m->desc.lag};
+    return RowMap{idx, row0, 0, 0};
+}
+
+static int64_t rows_of(const dcv_mlp* m, int batch) { return m->desc.model == DCV_MODEL_DEEPTICA ? 2 * (int64_t)batch : batch; }
+
+// wgrad split plan: enough workgroups to fill the chip twice, chunks a multiple of 32 rows
+static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t* splits) {
+    const int64_t tiles = (out <= 32 ? 1 : cdiv(out, 128)) * (in <= 32 ? 1 : cdiv(in, 128));
+    int64_t want = cdiv(2 * (int64_t)num_cus(), tiles);
+    int64_t max_by_rows = cdiv(rows, 256);
+    if (want > max_by_rows) want = max_by_rows;
+    if (want < 1) want = 1;
+    int64_t kc = cdiv(cdiv(rows, want), 32) * 32;
+    *k_chunk = kc;
+    *splits = cdiv(rows, kc);
+}
+
+static void mlp_free(dcv_mlp* m) {
+    if (!m) return;
+    auto f = [](void* p) { if (p) (void)hipFree(p); };
+    f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
+    f(m->spart); f(m->log); f(m->log_count); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
+    for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); }
+    delete m;
+}
+
+template <class T>
+static int dmalloc(T** p, size_t count) {
+    *p = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return DCV_ENOMEM;
+    }
+    return DCV_OK;
+}
+
+}  // namespace dcv
+
+// =================================================================== C-ABI
+extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
+    DCV_REQUIRE(desc && out, "dcv_mlp_create: null argument");
+    *out = nullptr;
+    const int L = desc->n_layers;
+    DCV_REQUIRE(desc->model == DCV_MODEL_DEEPTICA || desc->model == DCV_MODEL_AE, "dcv_mlp_create: unknown model %d", desc->model);
+    DCV_REQUIRE(L >= 1 && L <= DCV_MAX_LAYERS, "dcv_mlp_create: n_layers=%d out of range", L);
+    for (int l = 0; l <= L; ++l) DCV_REQUIRE(desc->dims[l] >= 1, "dcv_mlp_create: dims[%d]=%d", l, desc->dims[l]);
+    for (int l = 0; l < L; ++l)
+        DCV_REQUIRE(desc->act[l] >= DCV_ACT_NONE && desc->act[l] <= DCV_ACT_SOFTPLUS, "dcv_mlp_create: act[%d]=%d unsupported", l, desc->act[l]);
+    DCV_REQUIRE(desc->max_batch >= 1, "dcv_mlp_create: max_batch=%d", desc->max_batch);
+    if (desc->model == DCV_MODEL_DEEPTICA) {
+        DCV_REQUIRE(desc->dims[L] <= kMaxTicaDim, "dcv_mlp_create: Deep-TICA output dimension %d > %d", desc->dims[L], kMaxTicaDim);
+        DCV_REQUIRE(desc->lag >= 0, "dcv_mlp_create: lag=%d", desc->lag);
+    } else {
+        DCV_REQUIRE(desc->dims[L] == desc->dims[0], "dcv_mlp_create: autoencoder must map F=%d back to F (got %d)", desc->dims[0], desc->dims[L]);
+        DCV_REQUIRE(desc->latent_layer >= 1 && desc->latent_layer < L, "dcv_mlp_create: latent_layer=%d", desc->latent_layer);
+        DCV_REQUIRE(desc->dims[desc->latent_layer] <= 16, "dcv_mlp_create: latent dimension %d > 16", desc->dims[desc->latent_layer]);
+    }
+    dcv_mlp* m = new (std::nothrow) dcv_mlp();
+    DCV_REQUIRE(m, "dcv_mlp_create: out of host memory");
+    m->desc = *desc;
+    m->L = L;
+    m->d_out = desc->dims[L];
+    m->rows_cap = rows_of(m, desc->max_batch);
+    m->lr = desc->lr;
+    m->adam_t = 0;
+    m->last_batch = 0;
+    m->layers.resize(L);
+    int64_t off = 0;
+    int maxdim = 0;
+    int rc = DCV_OK;
+    for (int l = 0; l < L && rc == DCV_OK; ++l) {
+        LayerPlan& p = m->layers[l];
+        p.in = desc->dims[l];
+        p.out = desc->dims[l + 1];
+        p.act = desc->act[l];
+        p.w_off = off;
+        off += align_up((size_t)p.in * p.out, 4);
+        p.b_off = off;
+        off += align_up((size_t)p.out, 4);
+        p.ldh = align_up((size_t)p.out, 4);
+        if (p.out > maxdim) maxdim = p.out;
+        wgrad_plan(p.out, p.in, m->rows_cap, &p.k_chunk_cap, &p.max_splits);
+        // a smaller batch may use smaller chunks; bound the splits by the 256-row floor
+        p.max_splits = cdiv(m->rows_cap, 256) > p.max_splits ? p.max_splits : cdiv(m->rows_cap, 256);
+        if (p.max_splits < 1) p.max_splits = 1;
+        rc = dmalloc(&p.H, (size_t)m->rows_cap * p.ldh);
+        if (rc == DCV_OK) rc = dmalloc(&p.slab, (size_t)p.max_splits * p.in * p.out);
+        if (rc == DCV_OK) rc = dmalloc(&p.bpart, (size_t)cdiv(m->rows_cap, kColsumRows) * p.out);
+    }
+    m->n_params = off;
+    m->ld_dz = align_up((size_t)maxdim, 4);
+    const int d = m->d_out;
+    m->stats_len = desc->model == DCV_MODEL_DEEPTICA ? 2 * d + 2 * d * d : 1;
+    m->log_width = desc->model == DCV_MODEL_DEEPTICA ? 2 + 2 * d * d + d : 2;
+    m->spart_blocks = desc->model == DCV_MODEL_DEEPTICA ? (int)cdiv(desc->max_batch, kStatBlockRows) : (int)cdiv(m->rows_cap, 64);
+    const int dl = desc->model == DCV_MODEL_AE ? desc->dims[desc->latent_layer] : d;
+    if (rc == DCV_OK) rc = dmalloc(&m->params, (size_t)m->n_params);
+    if (rc == DCV_OK) rc = dmalloc(&m->grads, (size_t)m->n_params);
+    if (rc == DCV_OK) rc = dmalloc(&m->adam_m, (size_t)m->n_params);
+    if (rc == DCV_OK) rc = dmalloc(&m->adam_v, (size_t)m->n_params);
+    if (rc == DCV_OK) rc = dmalloc(&m->dZ[0], (size_t)m->rows_cap * m->ld_dz);
+    if (rc == DCV_OK) rc = dmalloc(&m->dZ[1], (size_t)m->rows_cap * m->ld_dz);
+    if (rc == DCV_OK) rc = dmalloc(&m->stats, (size_t)m->stats_len);
+    if (rc == DCV_OK) rc = dmalloc(&m->gradp, (size_t)(2 * kMaxTicaDim + 2 * kMaxTicaDim * kMaxTicaDim));
+    if (rc == DCV_OK) rc = dmalloc(&m->spart, (size_t)m->spart_blocks * m->stats_len);
+    if (rc == DCV_OK) rc = dmalloc(&m->log_count, 1);
+    if (rc == DCV_OK) rc = dmalloc(&m->feat_range, (size_t)desc->dims[0]);
+    if (rc == DCV_OK) rc = dmalloc(&m->ident, (size_t)dl * dl);
+    if (rc == DCV_OK) rc = dmalloc(&m->zeros_d, (size_t)dl);
+    if (rc == DCV_OK) rc = dmalloc(&m->ones_d, (size_t)dl);
+    m->proj_ws_bytes = dcv_project_linear_workspace(m->rows_cap, dl, dl);
+    if (rc == DCV_OK) rc = dmalloc(reinterpret_cast<char**>(&m->proj_ws), m->proj_ws_bytes);
+    m->log = nullptr;
+    m->log_cap = 0;
+    if (rc != DCV_OK) {
+        mlp_free(m);
+        return rc;
+    }
+    hipError_t e = hipMemset(m->params, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(m->grads, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(m->adam_m, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(m->adam_v, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(m->log_count, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(m->zeros_d, 0, dl * sizeof(float));
+    if (e == hipSuccess) e = hipMemset(m->ident, 0, (size_t)dl * dl * sizeof(float));
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(64), 0, 0, m->ones_d, (int64_t)dl, 1.f);
+        hipLaunchKernelGGL(fill_kernel, dim3(4), dim3(256), 0, 0, m->feat_range, (int64_t)desc->dims[0], 1.f);
+        std::vector<float> eye((size_t)dl * dl, 0.f);
+        for (int i = 0; i < dl; ++i) eye[(size_t)i * dl + i] = 1.f;
+        e = hipMemcpy(m->ident, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        set_error("dcv_mlp_create: initialisation failed: %s", hipGetErrorString(e));
+        mlp_free(m);
+        return DCV_EHIP;
+    }
+    *out = m;
+    return DCV_OK;
+}
+
+extern "C" void dcv_mlp_destroy(dcv_mlp* m) { mlp_free(m); }
+extern "C" int64_t dcv_mlp_num_params(const dcv_mlp* m) { return m ? m->n_params : 0; }
+extern "C" int64_t dcv_mlp_param_offset(const dcv_mlp* m, int32_t layer, int32_t which) {
+    if (!m || layer < 0 || layer >= m->L) return -1;
+    return which == 0 ? m->layers[layer].w_off : m->layers[layer].b_off;
+}
+extern "C" float* dcv_mlp_params(dcv_mlp* m) { return m ? m->params : nullptr; }
+extern "C" float* dcv_mlp_grads(dcv_mlp* m) { return m ? m->grads : nullptr; }
+extern "C" double* dcv_mlp_stats(dcv_mlp* m) { return m ? m->stats : nullptr; }
+extern "C" int32_t dcv_mlp_stats_len(const dcv_mlp* m) { return m ? m->stats_len : 0; }
+extern "C" int32_t dcv_mlp_log_width(const dcv_mlp* m) { return m ? m->log_width : 0; }
+
+extern "C" int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* stream) {
+    DCV_REQUIRE(m && params_h, "dcv_mlp_set_params: null argument");
+    hipStream_t s = as_stream(stream);
+    DCV_CHECK_HIP(hipMemcpyAsync(m->params, params_h, m->n_params * sizeof(float), hipMemcpyHostToDevice, s));
+    DCV_CHECK_HIP(hipMemsetAsync(m->adam_m, 0, m->n_params * sizeof(float), s));
+    DCV_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, m->n_params * sizeof(float), s));
+    DCV_CHECK_HIP(hipStreamSynchronize(s));
+    m->adam_t = 0;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_get_params(dcv_mlp* m, float* params_h, void* stream) {
+    DCV_REQUIRE(m && params_h, "dcv_mlp_get_params: null argument");
+    hipStream_t s = as_stream(stream);
+    DCV_CHECK_HIP(hipMemcpyAsync(params_h, m->params, m->n_params * sizeof(float), hipMemcpyDeviceToHost, s));
+    DCV_CHECK_HIP(hipStreamSynchronize(s));
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_set_lr(dcv_mlp* m, double lr) {
+    DCV_REQUIRE(m, "dcv_mlp_set_lr: null");
+    m->lr = lr;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_set_feature_range(dcv_mlp* m, const float* range_h, void* stream) {
+    DCV_REQUIRE(m && range_h, "dcv_mlp_set_feature_range: null argument");
+    hipStream_t s = as_stream(stream);
+    DCV_CHECK_HIP(hipMemcpyAsync(m->feat_range, range_h, m->desc.dims[0] * sizeof(float), hipMemcpyHostToDevice, s));
+    DCV_CHECK_HIP(hipStreamSynchronize(s));
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_reset_log(dcv_mlp* m, int32_t capacity, void* stream) {
+    DCV_REQUIRE(m && capacity >= 1, "dcv_mlp_reset_log: bad arguments");
+    hipStream_t s = as_stream(stream);
+    if (capacity > m->log_cap) {
+        DCV_CHECK_HIP(hipStreamSynchronize(s));
+        if (m->log) (void)hipFree(m->log);
+        m->log = nullptr;
+        m->log_cap = 0;
+        int rc = dmalloc(&m->log, (size_t)capacity * m->log_width);
+        if (rc) return rc;
+        m->log_cap = capacity;
+    }
+    DCV_CHECK_HIP(hipMemsetAsync(m->log_count, 0, sizeof(int), s));
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, int32_t* n_records, void* stream) {
+    DCV_REQUIRE(m && out_h && n_records, "dcv_mlp_read_log: null argument");
+    hipStream_t s = as_stream(stream);
+    int cnt = 0;
+    DCV_CHECK_HIP(hipMemcpyAsync(&cnt, m->log_count, sizeof(int), hipMemcpyDeviceToHost, s));
+    DCV_CHECK_HIP(hipStreamSynchronize(s));
+    if (cnt > m->log_cap) cnt = m->log_cap;
+    if (cnt > max_records) cnt = max_records;
+    if (cnt > 0) {
+        DCV_CHECK_HIP(hipMemcpyAsync(out_h, m->log, (size_t)cnt * m->log_width * sizeof(double), hipMemcpyDeviceToHost, s));
+        DCV_CHECK_HIP(hipStreamSynchronize(s));
+    }
+    *n_records = cnt;
+    return DCV_OK;
+}
+
+// forward through layers [0, n_run) for `rows` logical rows
+static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& rows_map, int64_t rows, int n_run, hipStream_t s) {
+    for (int l = 0; l < n_run; ++l) {
+        LayerPlan& p = m->layers[l];
+        Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
+        Operand B = make_operand(m->params + p.w_off, p.in, p.in);
+        EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act};
+        int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s);
+        if (rc) return rc;
+    }
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                               void* stream) {
+    DCV_REQUIRE(m && Xn_d, "dcv_mlp_forward: null argument");
+    DCV_REQUIRE(batch >= 1 && batch <= m->desc.max_batch, "dcv_mlp_forward: batch=%d exceeds max_batch=%d", batch, m->desc.max_batch);
+    DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_forward: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
+    hipStream_t s = as_stream(stream);
+    const RowMap rm = batch_rows(m, idx_d, row0, batch);
+    const int64_t R = rows_of(m, batch);
+    int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s);
+    if (rc) return rc;
+    const LayerPlan& last = m->layers[m->L - 1];
+    if (m->desc.model == DCV_MODEL_DEEPTICA) {
+        const int nb = (int)cdiv(batch, kStatBlockRows);
+        hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, last.H,
+                           last.ldh, batch, m->d_out, m->spart);
+        DCV_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(m->stats_len), dim3(64), 0, s, m->spart, nb, m->stats_len, m->stats);
+        DCV_CHECK_LAUNCH();
+    } else {
+        const int nb = (int)cdiv(R, 64);
+        hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart);
+        DCV_CHECK_LAUNCH();
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, m->spart, nb, 1, m->stats);
+        DCV_CHECK_LAUNCH();
+    }
+    m->last_batch = batch;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                                int64_t global_batch, int32_t train, void* stream) {
+    DCV_REQUIRE(m && Xn_d, "dcv_mlp_backward: null argument");
+    if (m->last_batch != batch) {
+        set_error("dcv_mlp_backward: batch=%d does not match the preceding forward (%d)", batch, m->last_batch);
+        return DCV_ESTATE;
+    }
+    DCV_REQUIRE(global_batch >= batch, "dcv_mlp_backward: global_batch=%lld < batch=%d", (long long)global_batch, batch);
+    DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp_backward: call dcv_mlp_reset_log first");
+    hipStream_t s = as_stream(stream);
+    const RowMap rm = batch_rows(m, idx_d, row0, batch);
+    const int64_t R = rows_of(m, batch);
+    const int L = m->L;
+    const LayerPlan& last = m->layers[L - 1];
+    float* dz_cur = m->dZ[0];
+    float* dz_nxt = m->dZ[1];
+    if (m->desc.model == DCV_MODEL_DEEPTICA) {
+        hipLaunchKernelGGL(tica_grad_kernel, dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
+                           train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
+        DCV_CHECK_LAUNCH();
+        if (!train) return DCV_OK;
+        hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(batch, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
+                           m->gradp, last.act, dz_cur, m->ld_dz);
+        DCV_CHECK_LAUNCH();
+    } else {
+        const int F = m->desc.dims[0];
+        hipLaunchKernelGGL(ae_log_kernel, dim3(1), dim3(64), 0, s, m->stats, (double)global_batch, F, m->log, m->log_count, m->log_cap, m->log_width);
+        DCV_CHECK_LAUNCH();
+        if (!train) return DCV_OK;
+        const float scale = (float)(2.0 / ((double)global_batch * (double)F));
+        int64_t blocks = cdiv(R * F, 256);
+        const int64_t cap = (int64_t)num_cus() * 16;
+        if (blocks > cap) blocks = cap;
+        hipLaunchKernelGGL(ae_dY_kernel, dim3((unsigned)blocks), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, F, m->feat_range, scale,
+                           last.act, dz_cur, m->ld_dz);
+        DCV_CHECK_LAUNCH();
+    }
+    ReduceArgs ra;
+    ra.L = L;
+    for (int l = L - 1; l >= 0; --l) {
+        LayerPlan& p = m->layers[l];
+        // wgrad: dW = dZ^T In  (M = out, N = in, K = rows)
+        int64_t kc, splits;
+        wgrad_plan(p.out, p.in, R, &kc, &splits);
+        if (splits > p.max_splits) {
+            splits = p.max_splits;
+            kc = cdiv(cdiv(R, splits), 32) * 32;
+            splits = cdiv(R, kc);
+        }
+        Operand A = make_operand(dz_cur, m->ld_dz, p.out);
+        Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
+        EpiSlab epi{p.slab, p.out, p.in, 1, 0};
+        int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
+        if (rc) return rc;
+        const int bblocks = (int)cdiv(R, kColsumRows);
+        hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, p.out, m->ld_dz, p.bpart);
+        DCV_CHECK_LAUNCH();
+        ReduceDesc& rd = ra.l[l];
+        rd.slab = p.slab;
+        rd.bpart = p.bpart;
+        rd.w_off = p.w_off;
+        rd.b_off = p.b_off;
+        rd.w_count = (int64_t)p.out * p.in;
+        rd.out = p.out;
+        rd.splits = (int)splits;
+        rd.bblocks = bblocks;
+        if (l > 0) {
+            // dgrad: dZ_prev = (dZ W) * act'(H_prev)   (M = rows, N = in, K = out)
+            const LayerPlan& q = m->layers[l - 1];
+            Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
+            Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
+            EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act};
+            rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s);
+            if (rc) return rc;
+            float* tmp = dz_cur;
+            dz_cur = dz_nxt;
+            dz_nxt = tmp;
+        }
+    }
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3(256, L), dim3(256), 0, s, ra, m->grads, 1.f);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_apply(dcv_mlp* m, void* stream) {
+    DCV_REQUIRE(m, "dcv_mlp_apply: null");
+    hipStream_t s = as_stream(stream);
+    m->adam_t += 1;
+    const double b1 = m->desc.beta1, b2 = m->desc.beta2;
+    const double bc1 = 1.0 - pow(b1, (double)m->adam_t);
+    const double bc2 = 1.0 - pow(b2, (double)m->adam_t);
+    int64_t blocks = cdiv(m->n_params, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->params, m->grads, m->adam_m, m->adam_v, m->n_params,
+                       (float)(m->lr / bc1), (float)sqrt(bc2), (float)b1, (float)b2, (float)m->desc.eps, (float)m->desc.weight_decay);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                                  void* stream) {
+    int rc = dcv_mlp_forward(m, Xn_d, ld, idx_d, row0, batch, stream);
+    if (rc) return rc;
+    rc = dcv_mlp_backward(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream);
+    if (rc) return rc;
+    return dcv_mlp_apply(m, stream);
+}
+
+extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                                 void* stream) {
+    int rc = dcv_mlp_forward(m, Xn_d, ld, idx_d, row0, batch, stream);
+    if (rc) return rc;
+    return dcv_mlp_backward(m, Xn_d, ld, idx_d, row0, batch, batch, 0, stream);
+}
+
+extern "C" int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld, const float* tmean_d, const float* tevecs_d,
+                             const float* pmean_d, const float* prange_d, float* out_d, float* minmax_d, void* stream) {
+    DCV_REQUIRE(m && Xn_d && n >= 1, "dcv_mlp_infer: bad arguments");
+    DCV_REQUIRE(n <= m->rows_cap, "dcv_mlp_infer: n=%lld exceeds the row capacity %lld (chunk the call)", (long long)n, (long long)m->rows_cap);
+    DCV_REQUIRE((tmean_d == nullptr) == (tevecs_d == nullptr), "dcv_mlp_infer: tmean/tevecs must come together");
+    hipStream_t s = as_stream(stream);
+    const int n_run = m->desc.model == DCV_MODEL_AE ? m->desc.latent_layer : m->L;
+    const RowMap rm = identity_rows();
+    int rc = run_forward(m, Xn_d, ld, rm, n, n_run, s);
+    if (rc) return rc;
+    const LayerPlan& last = m->layers[n_run - 1];
+    const int d = last.out;
+    // y = (h - tmean) @ tevecs ; out = (y - pmean) / prange   -- the linear projection kernel
+    return dcv_project_linear(last.H, n, d, last.ldh, tmean_d ? tmean_d : m->zeros_d, m->ones_d, tevecs_d ? tevecs_d : m->ident, d,
+                              nullptr, pmean_d, prange_d, out_d, minmax_d, m->proj_ws, m->proj_ws_bytes, stream);
+}

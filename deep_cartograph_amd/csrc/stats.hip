@@ -1,0 +1,241 @@
+// Column statistics and normalisation: HBM-bound streaming passes over the frames x features
+// matrix.  Lanes run along the feature axis (16-byte loads, whole rows per wave), rows are
+// strided over the block; partial results per block are combined in a fixed order, so the
+// result is deterministic.
+#include "common.h"
+
+namespace dcv {
+
+constexpr int kStatsThreads = 256;
+constexpr int kStatsMaxBlocks = 2048;
+
+struct StatsGeom {
+    int cpb;      // column groups (of VEC columns) handled per pass by one block
+    int rpp;      // rows per pass
+    int ncb;      // column-block passes
+};
+
+template <int VEC>
+__host__ __device__ inline StatsGeom stats_geom(int F) {
+    int ng = (F + VEC - 1) / VEC;
+    StatsGeom g;
+    g.cpb = ng < kStatsThreads ? ng : kStatsThreads;
+    g.rpp = kStatsThreads / g.cpb;
+    g.ncb = (ng + g.cpb - 1) / g.cpb;
+    return g;
+}
+
+// partial layout: part[block][stat][F], stat = 0 sum, 1 sumsq, 2 min, 3 max (float64)
+template <int VEC>
+__global__ __launch_bounds__(kStatsThreads) void col_stats_kernel(const float* __restrict__ X, int64_t n, int F,
+                                                                  int64_t ld, double* __restrict__ part) {
+    const StatsGeom g = stats_geom<VEC>(F);
+    const int t = threadIdx.x;
+    const int cg = t % g.cpb;
+    const int rl = t / g.cpb;
+    const bool active = rl < g.rpp;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double* s_sum = reinterpret_cast<double*>(smem);               // [256][VEC]
+    double* s_sq = s_sum + kStatsThreads * VEC;                     // [256][VEC]
+    float* s_mn = reinterpret_cast<float*>(s_sq + kStatsThreads * VEC);
+    float* s_mx = s_mn + kStatsThreads * VEC;
+
+    // contiguous block of rows per workgroup
+    const int64_t rows_per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t r_begin = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r_end = r_begin + rows_per_block < n ? r_begin + rows_per_block : n;
+    double* my_part = part + (int64_t)blockIdx.x * 4 * F;
+
+    for (int cb = 0; cb < g.ncb; ++cb) {
+        const int col = (cb * g.cpb + cg) * VEC;
+        const bool col_ok = active && col < F;
+        double sum[VEC], sq[VEC];
+        float mn[VEC], mx[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            sum[v] = 0.0;
+            sq[v] = 0.0;
+            mn[v] = INFINITY;
+            mx[v] = -INFINITY;
+        }
+        if (col_ok) {
+            const float* base = X + col;
+            int64_t r = r_begin + rl;
+            // 4 independent row loads in flight
+            for (; r + 3 * (int64_t)g.rpp < r_end; r += 4 * (int64_t)g.rpp) {
+                float x[4][VEC];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float* p = base + (r + (int64_t)u * g.rpp) * ld;
+                    if constexpr (VEC == 4) {
+                        const float4 q = *reinterpret_cast<const float4*>(p);
+                        x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
+                    } else {
+                        x[u][0] = *p;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v) {
+                        const double d = (double)x[u][v];
+                        sum[v] += d;
+                        sq[v] = fma(d, d, sq[v]);
+                        mn[v] = fminf(mn[v], x[u][v]);
+                        mx[v] = fmaxf(mx[v], x[u][v]);
+                    }
+            }
+            for (; r < r_end; r += g.rpp) {
+                const float* p = base + r * ld;
+                float x[VEC];
+                if constexpr (VEC == 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(p);
+                    x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+                } else {
+                    x[0] = *p;
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const double d = (double)x[v];
+                    sum[v] += d;
+                    sq[v] = fma(d, d, sq[v]);
+                    mn[v] = fminf(mn[v], x[v]);
+                    mx[v] = fmaxf(mx[v], x[v]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            s_sum[t * VEC + v] = sum[v];
+            s_sq[t * VEC + v] = sq[v];
+            s_mn[t * VEC + v] = mn[v];
+            s_mx[t * VEC + v] = mx[v];
+        }
+        __syncthreads();
+        if (rl == 0 && col < F) {
+            // fixed-order combine over the row lanes of this block
+            for (int v = 0; v < VEC && col + v < F; ++v) {
+                double a = 0.0, b = 0.0;
+                float lo = INFINITY, hi = -INFINITY;
+                for (int q = 0; q < g.rpp; ++q) {
+                    const int tt = q * g.cpb + cg;
+                    a += s_sum[tt * VEC + v];
+                    b += s_sq[tt * VEC + v];
+                    lo = fminf(lo, s_mn[tt * VEC + v]);
+                    hi = fmaxf(hi, s_mx[tt * VEC + v]);
+                }
+                my_part[0 * F + col + v] = a;
+                my_part[1 * F + col + v] = b;
+                my_part[2 * F + col + v] = (double)lo;
+                my_part[3 * F + col + v] = (double)hi;
+            }
+        }
+    }
+}
+
+__global__ void col_stats_final_kernel(const double* __restrict__ part, int nblocks, int F, double* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // index into [4][F]
+    if (i >= 4 * F) return;
+    const int stat = i / F;
+    double acc = stat == 2 ? INFINITY : (stat == 3 ? -INFINITY : 0.0);
+    for (int b = 0; b < nblocks; ++b) {
+        const double v = part[(int64_t)b * 4 * F + i];
+        if (stat < 2) acc += v;
+        else if (stat == 2) acc = fmin(acc, v);
+        else acc = fmax(acc, v);
+    }
+    out[i] = acc;
+}
+
+static int stats_blocks(int64_t n, int F) {
+    // enough rows per block to amortise the combine; at most kStatsMaxBlocks
+    int64_t b = cdiv(n, 64);
+    if (b > kStatsMaxBlocks) b = kStatsMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------------------ normalise
+template <int VEC>
+__global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t n,
+                                                        int F, int64_t ldx, int64_t ldy,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ range) {
+    const int ng = (F + VEC - 1) / VEC;
+    const int64_t total = n * ng;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ng;
+        const int c = (int)(i - r * ng) * VEC;
+        if constexpr (VEC == 4) {
+            const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + c);
+            const float4 m = *reinterpret_cast<const float4*>(mean + c);
+            const float4 s = *reinterpret_cast<const float4*>(range + c);
+            float4 y;
+            // true IEEE subtraction and division, as torch's sub_ / div_ (cv_calculator.py:833-835)
+            y.x = __fdiv_rn(__fsub_rn(x.x, m.x), s.x);
+            y.y = __fdiv_rn(__fsub_rn(x.y, m.y), s.y);
+            y.z = __fdiv_rn(__fsub_rn(x.z, m.z), s.z);
+            y.w = __fdiv_rn(__fsub_rn(x.w, m.w), s.w);
+            *reinterpret_cast<float4*>(Y + r * ldy + c) = y;
+        } else {
+            Y[r * ldy + c] = __fdiv_rn(__fsub_rn(X[r * ldx + c], mean[c]), range[c]);
+        }
+    }
+}
+
+}  // namespace dcv
+
+using namespace dcv;
+
+static bool vec4_ok(const void* p, int F, int64_t ld) {
+    return (F % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0);
+}
+
+extern "C" size_t dcv_col_stats_workspace(int64_t n, int32_t F) {
+    if (n <= 0 || F <= 0) return 0;
+    return (size_t)stats_blocks(n, F) * 4 * (size_t)F * sizeof(double);
+}
+
+extern "C" int dcv_col_stats(const float* X_d, int64_t n, int32_t F, int64_t ld, double* out_d, void* ws_d,
+                             size_t ws_bytes, void* stream) {
+    DCV_REQUIRE(X_d && out_d && n > 0 && F > 0 && ld >= F, "dcv_col_stats: bad arguments (n=%lld F=%d ld=%lld)",
+                (long long)n, F, (long long)ld);
+    DCV_REQUIRE(ws_d && ws_bytes >= dcv_col_stats_workspace(n, F), "dcv_col_stats: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int nb = stats_blocks(n, F);
+    double* part = static_cast<double*>(ws_d);
+    if (vec4_ok(X_d, F, ld)) {
+        const size_t lds = kStatsThreads * 4 * (2 * sizeof(double) + 2 * sizeof(float));
+        hipLaunchKernelGGL(col_stats_kernel<4>, dim3(nb), dim3(kStatsThreads), lds, s, X_d, n, F, ld, part);
+    } else {
+        const size_t lds = kStatsThreads * 1 * (2 * sizeof(double) + 2 * sizeof(float));
+        hipLaunchKernelGGL(col_stats_kernel<1>, dim3(nb), dim3(kStatsThreads), lds, s, X_d, n, F, ld, part);
+    }
+    DCV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(col_stats_final_kernel, dim3((4 * F + 255) / 256), dim3(256), 0, s, part, nb, F, out_d);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+extern "C" int dcv_normalize(const float* X_d, float* Y_d, int64_t n, int32_t F, int64_t ldx, int64_t ldy,
+                             const float* mean_d, const float* range_d, void* stream) {
+    DCV_REQUIRE(X_d && Y_d && mean_d && range_d && n > 0 && F > 0 && ldx >= F && ldy >= F,
+                "dcv_normalize: bad arguments");
+    hipStream_t s = as_stream(stream);
+    const bool v4 = vec4_ok(X_d, F, ldx) && vec4_ok(Y_d, F, ldy) && ((reinterpret_cast<uintptr_t>(mean_d) & 15) == 0) &&
+                    ((reinterpret_cast<uintptr_t>(range_d) & 15) == 0);
+    const int64_t total = n * (v4 ? F / 4 : F);
+    int64_t blocks = cdiv(total, 256);
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    if (v4)
+        hipLaunchKernelGGL(normalize_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, X_d, Y_d, n, F, ldx, ldy, mean_d,
+                           range_d);
+    else
+        hipLaunchKernelGGL(normalize_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, X_d, Y_d, n, F, ldx, ldy, mean_d,
+                           range_d);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}

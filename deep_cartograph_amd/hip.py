@@ -1,0 +1,372 @@
+"""Thin torch-tensor front end of the C-ABI (include/dcv.h).
+
+torch is plumbing here: it owns device memory and the current stream; every number is
+produced by a HIP kernel of libdcv.so.  All functions require CUDA(HIP) tensors and raise
+otherwise -- there is no CPU path.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import DcvError, check
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DcvError("deep_cartograph_amd kernels need tensors on an MI355X (cuda) device; got a CPU tensor")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ws(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _check_matrix(X: torch.Tensor, dtype=torch.float32):
+    if X.dim() != 2 or X.dtype != dtype or X.stride(1) != 1:
+        raise DcvError(f"expected a row-major 2-D {dtype} tensor, got shape {tuple(X.shape)} dtype {X.dtype} strides {X.stride()}")
+
+
+# ------------------------------------------------------------------------------- statistics
+def col_stats_raw(X: torch.Tensor) -> torch.Tensor:
+    """[4, F] float64: sum, sum of squares, min, max (dcv_col_stats)."""
+    _require_gpu(X)
+    _check_matrix(X)
+    lib = _lib.load()
+    n, F = X.shape
+    out = torch.empty(4, F, dtype=torch.float64, device=X.device)
+    ws = _ws(lib.dcv_col_stats_workspace(n, F), X.device)
+    check(lib.dcv_col_stats(_ptr(X), n, F, X.stride(0), _ptr(out), _ptr(ws), ws.numel(), _stream()), "dcv_col_stats")
+    return out
+
+
+def finalize_stats(raw: torch.Tensor, n: int) -> dict:
+    """mean / std(ddof=1) / min / max as float32 NumPy arrays from (all-reduced) raw sums."""
+    r = raw.detach().cpu().numpy()
+    mean = r[0] / n
+    var = (r[1] - n * mean * mean) / max(n - 1, 1)
+    std = np.sqrt(np.maximum(var, 0.0))
+    return {"mean": mean.astype(np.float32), "std": std.astype(np.float32),
+            "min": r[2].astype(np.float32), "max": r[3].astype(np.float32)}
+
+
+def normalize(X: torch.Tensor, mean: torch.Tensor, rng: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(x - mean) / range in float32; ``out`` may be X itself (in place)."""
+    _require_gpu(X, mean, rng, out)
+    _check_matrix(X)
+    if out is None:
+        out = torch.empty_like(X)
+    _check_matrix(out)
+    n, F = X.shape
+    check(_lib.load().dcv_normalize(_ptr(X), _ptr(out), n, F, X.stride(0), out.stride(0), _ptr(mean), _ptr(rng), _stream()),
+          "dcv_normalize")
+    return out
+
+
+# ------------------------------------------------------------------------------- covariance
+def lagged_cov_raw(X: torch.Tensor, n_pairs: int, lag: int, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Raw sums [a (F) | b (F) | A (F*F) | B (F*F)] float64 over pairs (i, i+lag), i < n_pairs."""
+    _require_gpu(X, shift)
+    _check_matrix(X)
+    lib = _lib.load()
+    n, F = X.shape
+    if n_pairs + lag > n:
+        raise DcvError(f"lagged_cov: n_pairs + lag = {n_pairs + lag} exceeds the {n} rows available")
+    out = torch.empty(2 * F + 2 * F * F, dtype=torch.float64, device=X.device)
+    ws = _ws(lib.dcv_lagged_cov_workspace(n_pairs, F, lag), X.device)
+    check(lib.dcv_lagged_cov(_ptr(X), n_pairs, F, X.stride(0), lag, _ptr(shift), _ptr(out), _ptr(ws), ws.numel(), _stream()),
+          "dcv_lagged_cov")
+    return out
+
+
+def covariances_from_raw(raw: np.ndarray, n_pairs: int, F: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(mu_z, C0, Ctau) in float64 from (all-reduced) raw sums, following
+    mlcolvar TICA.compute: mean of x_t removed from both, both
+    matrices divided by the number of pairs and symmetrised."""
+    a = raw[:F]
+    b = raw[F:2 * F]
+    A = raw[2 * F:2 * F + F * F].reshape(F, F)
+    B = raw[2 * F + F * F:].reshape(F, F)
+    P = float(n_pairs)
+    delta = a / P
+    C0 = A / P - np.outer(delta, delta)
+    Ct = B / P - np.outer(delta, b / P)
+    C0 = 0.5 * (C0 + C0.T)
+    Ct = 0.5 * (Ct + Ct.T)
+    return delta, C0, Ct
+
+
+# ------------------------------------------------------------------------------- projection
+def project_linear(X: torch.Tensor, W: torch.Tensor, *, fmean=None, frange=None, bias=None, cvmean=None, cvrange=None,
+                   want_out=True, want_minmax=False):
+    """out = (((x - fmean)/frange) @ W + bias - cvmean)/cvrange ; optional per-column min/max."""
+    _require_gpu(X, W, fmean, frange, bias, cvmean, cvrange)
+    _check_matrix(X)
+    lib = _lib.load()
+    n, F = X.shape
+    if W.dim() != 2 or W.shape[0] != F or not W.is_contiguous() or W.dtype != torch.float32:
+        raise DcvError("project_linear: W must be a contiguous float32 F x d tensor")
+    d = W.shape[1]
+    out = torch.empty(n, d, dtype=torch.float32, device=X.device) if want_out else None
+    mm = torch.empty(2, d, dtype=torch.float32, device=X.device) if want_minmax else None
+    ws = _ws(lib.dcv_project_linear_workspace(n, F, d), X.device)
+    check(lib.dcv_project_linear(_ptr(X), n, F, X.stride(0), _ptr(fmean), _ptr(frange), _ptr(W), d, _ptr(bias),
+                                 _ptr(cvmean), _ptr(cvrange), _ptr(out), _ptr(mm), _ptr(ws), ws.numel(), _stream()),
+          "dcv_project_linear")
+    return out, mm
+
+
+# ------------------------------------------------------------------------------- GEMM block
+def gemm(mode: str, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """Building block (tests): 'nt' A[M,K].B[N,K]^T, 'nn' A[M,K].B[K,N], 'tn' A[K,M]^T.B[K,N]."""
+    _require_gpu(A, B)
+    _check_matrix(A)
+    _check_matrix(B)
+    m = {"nt": 0, "nn": 1, "tn": 2}[mode]
+    if m == 0:
+        M, K = A.shape
+        N = B.shape[0]
+    elif m == 1:
+        M, K = A.shape
+        N = B.shape[1]
+    else:
+        K, M = A.shape
+        N = B.shape[1]
+    Cm = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    check(_lib.load().dcv_gemm_f32(m, _ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(Cm), Cm.stride(0), M, N, K, _stream()),
+          "dcv_gemm_f32")
+    return Cm
+
+
+# ------------------------------------------------------------------------------- k-means
+def kmeans_step(P: torch.Tensor, centers: torch.Tensor, labels: torch.Tensor, offset: Optional[torch.Tensor] = None,
+                want_mindist=False):
+    """One Lloyd E-step + accumulation.  Returns (acc, mindist) with
+    acc = [sums (k*d) | counts (k) | inertia | changed] float64 on the device."""
+    _require_gpu(P, centers, labels, offset)
+    _check_matrix(P, torch.float64)
+    lib = _lib.load()
+    n, d = P.shape
+    k = centers.shape[0]
+    acc = torch.empty(k * d + k + 2, dtype=torch.float64, device=P.device)
+    md = torch.empty(n, dtype=torch.float64, device=P.device) if want_mindist else None
+    ws = _ws(lib.dcv_kmeans_workspace(n, d, k), P.device)
+    check(lib.dcv_kmeans_step(_ptr(P), n, d, _ptr(offset), _ptr(centers), k, _ptr(labels), _ptr(acc), _ptr(md), _ptr(ws), ws.numel(), _stream()),
+          "dcv_kmeans_step")
+    return acc, md
+
+
+def nearest_rows(P: torch.Tensor, centers: torch.Tensor, row_offset: int = 0):
+    """Per centroid: (distance, global row) of the nearest point (np.linalg.norm, first index on ties)."""
+    _require_gpu(P, centers)
+    _check_matrix(P, torch.float64)
+    lib = _lib.load()
+    n, d = P.shape
+    k = centers.shape[0]
+    dist = torch.empty(k, dtype=torch.float64, device=P.device)
+    rows = torch.empty(k, dtype=torch.int64, device=P.device)
+    ws = _ws(lib.dcv_nearest_rows_workspace(n, d, k), P.device)
+    check(lib.dcv_nearest_rows(_ptr(P), n, d, _ptr(centers), k, row_offset, _ptr(dist), _ptr(rows), _ptr(ws), ws.numel(), _stream()),
+          "dcv_nearest_rows")
+    return dist, rows
+
+
+def nearest_point(train: torch.Tensor, sup: torch.Tensor) -> torch.Tensor:
+    _require_gpu(train, sup)
+    _check_matrix(train, torch.float64)
+    _check_matrix(sup, torch.float64)
+    nn = torch.empty(sup.shape[0], dtype=torch.int64, device=sup.device)
+    check(_lib.load().dcv_nearest_point(_ptr(train.contiguous()), train.shape[0], _ptr(sup.contiguous()), sup.shape[0],
+                                        train.shape[1], _ptr(nn), _stream()), "dcv_nearest_point")
+    return nn
+
+
+# ------------------------------------------------------------------------------- MLP engine
+class Mlp:
+    """Owner of a ``dcv_mlp`` handle (Deep-TICA or autoencoder chain of Linear layers).
+
+    ``dims`` = [F, ..., out]; ``acts`` one activation name per Linear.  Parameters are kept
+    in the library's flat device buffer; ``set_linear`` / ``get_linear`` move torch-layout
+    (out x in weight, out bias) tensors in and out."""
+
+    def __init__(self, model: str, dims, acts, *, max_batch: int, lag: int = 0, tica_reg: float = 1e-6,
+                 latent_layer: Optional[int] = None, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
+                 weight_decay: float = 0.0, device="cuda"):
+        import ctypes as C
+
+        if not torch.cuda.is_available():
+            raise DcvError("the MLP engine needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        self.model = model
+        self.dims = [int(x) for x in dims]
+        self.acts = list(acts)
+        L = len(self.dims) - 1
+        if len(self.acts) != L:
+            raise DcvError("one activation per Linear layer expected")
+        desc = _lib.MlpDesc()
+        desc.model = {"deep_tica": _lib.MODEL_DEEPTICA, "ae": _lib.MODEL_AE}[model]
+        desc.n_layers = L
+        for i, v in enumerate(self.dims):
+            desc.dims[i] = v
+        for i, a in enumerate(self.acts):
+            if a not in _lib.ACT:
+                raise DcvError(f"activation {a!r} is not implemented by the HIP engine")
+            desc.act[i] = _lib.ACT[a]
+        desc.latent_layer = L if latent_layer is None else int(latent_layer)
+        desc.lag = int(lag)
+        desc.max_batch = int(max_batch)
+        desc.tica_reg = float(tica_reg)
+        desc.lr, desc.beta1, desc.beta2, desc.eps, desc.weight_decay = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+        h = C.c_void_p()
+        check(self.lib.dcv_mlp_create(C.byref(desc), C.byref(h)), "dcv_mlp_create")
+        self.h = h
+        self.L = L
+        self.latent_layer = desc.latent_layer
+        self.max_batch = int(max_batch)
+        self.rows_cap = 2 * self.max_batch if model == "deep_tica" else self.max_batch
+        self.n_params = self.lib.dcv_mlp_num_params(self.h)
+        self.offsets = [(self.lib.dcv_mlp_param_offset(self.h, l, 0), self.lib.dcv_mlp_param_offset(self.h, l, 1)) for l in range(L)]
+        self.log_width = self.lib.dcv_mlp_log_width(self.h)
+        self.stats_len = self.lib.dcv_mlp_stats_len(self.h)
+        self._log_cap = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dcv_mlp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- parameters
+    def set_linears(self, linears):
+        """linears: list of (weight[out,in], bias[out]) CPU float32 tensors / arrays."""
+        flat = np.zeros(self.n_params, dtype=np.float32)
+        for l, (w, b) in enumerate(linears):
+            w = np.asarray(w, dtype=np.float32)
+            b = np.asarray(b, dtype=np.float32)
+            if w.shape != (self.dims[l + 1], self.dims[l]) or b.shape != (self.dims[l + 1],):
+                raise DcvError(f"layer {l}: expected weight {(self.dims[l + 1], self.dims[l])}, got {w.shape}")
+            wo, bo = self.offsets[l]
+            flat[wo: wo + w.size] = w.ravel()
+            flat[bo: bo + b.size] = b
+        check(self.lib.dcv_mlp_set_params(self.h, flat.ctypes.data, _stream()), "dcv_mlp_set_params")
+
+    def get_linears(self):
+        flat = np.empty(self.n_params, dtype=np.float32)
+        check(self.lib.dcv_mlp_get_params(self.h, flat.ctypes.data, _stream()), "dcv_mlp_get_params")
+        out = []
+        for l in range(self.L):
+            wo, bo = self.offsets[l]
+            o, i = self.dims[l + 1], self.dims[l]
+            out.append((flat[wo: wo + o * i].reshape(o, i).copy(), flat[bo: bo + o].copy()))
+        return out
+
+    def _flat_view(self, ptr, n, dtype):
+        # a torch view over library-owned device memory (for all-reduce / inspection)
+        import ctypes as C
+
+        class _Holder:
+            pass
+
+        itemsize = torch.tensor([], dtype=dtype).element_size()
+        holder = _Holder()
+        holder.__cuda_array_interface__ = {
+            "shape": (n,), "typestr": {torch.float32: "<f4", torch.float64: "<f8"}[dtype],
+            "data": (int(ptr), False), "version": 2, "strides": (itemsize,)}
+        return torch.as_tensor(holder, device=self.device)
+
+    def grads_view(self) -> torch.Tensor:
+        return self._flat_view(self.lib.dcv_mlp_grads(self.h), self.n_params, torch.float32)
+
+    def params_view(self) -> torch.Tensor:
+        return self._flat_view(self.lib.dcv_mlp_params(self.h), self.n_params, torch.float32)
+
+    def stats_view(self) -> torch.Tensor:
+        return self._flat_view(self.lib.dcv_mlp_stats(self.h), self.stats_len, torch.float64)
+
+    def set_lr(self, lr: float):
+        check(self.lib.dcv_mlp_set_lr(self.h, float(lr)), "dcv_mlp_set_lr")
+
+    def set_feature_range(self, rng):
+        r = np.ascontiguousarray(np.asarray(rng, dtype=np.float32))
+        check(self.lib.dcv_mlp_set_feature_range(self.h, r.ctypes.data, _stream()), "dcv_mlp_set_feature_range")
+
+    # -- steps
+    def _args(self, Xn, idx, row0, batch):
+        _require_gpu(Xn, idx)
+        _check_matrix(Xn)
+        if idx is not None and (idx.dtype != torch.int64 or not idx.is_contiguous()):
+            raise DcvError("batch indices must be a contiguous int64 device tensor")
+        return _ptr(Xn), Xn.stride(0), _ptr(idx), int(row0), int(batch)
+
+    def forward(self, Xn, idx=None, row0=0, batch=None):
+        batch = int(batch if batch is not None else idx.numel())
+        check(self.lib.dcv_mlp_forward(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_forward")
+
+    def backward(self, Xn, idx=None, row0=0, batch=None, global_batch=None, train=True):
+        batch = int(batch if batch is not None else idx.numel())
+        gb = int(global_batch if global_batch is not None else batch)
+        check(self.lib.dcv_mlp_backward(self.h, *self._args(Xn, idx, row0, batch), gb, 1 if train else 0, _stream()), "dcv_mlp_backward")
+
+    def apply(self):
+        check(self.lib.dcv_mlp_apply(self.h, _stream()), "dcv_mlp_apply")
+
+    def train_step(self, Xn, idx=None, row0=0, batch=None):
+        batch = int(batch if batch is not None else idx.numel())
+        check(self.lib.dcv_mlp_train_step(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_train_step")
+
+    def eval_step(self, Xn, idx=None, row0=0, batch=None):
+        batch = int(batch if batch is not None else idx.numel())
+        check(self.lib.dcv_mlp_eval_step(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_eval_step")
+
+    # -- metrics log
+    def reset_log(self, capacity: int):
+        check(self.lib.dcv_mlp_reset_log(self.h, int(capacity), _stream()), "dcv_mlp_reset_log")
+        self._log_cap = max(self._log_cap, int(capacity))
+
+    def read_log(self) -> np.ndarray:
+        import ctypes as C
+
+        out = np.empty((max(self._log_cap, 1), self.log_width), dtype=np.float64)
+        n = C.c_int32(0)
+        check(self.lib.dcv_mlp_read_log(self.h, out.ctypes.data, out.shape[0], C.byref(n), _stream()), "dcv_mlp_read_log")
+        return out[: n.value].copy()
+
+    # -- inference
+    def infer(self, Xn, *, tmean=None, tevecs=None, pmean=None, prange=None, want_out=True, want_minmax=False):
+        """Forward of every row of Xn (chunked to the engine's row capacity).
+        Returns (out [n, d] or None, minmax [2, d] or None)."""
+        _require_gpu(Xn, tmean, tevecs, pmean, prange)
+        _check_matrix(Xn)
+        n = Xn.shape[0]
+        d = self.dims[self.latent_layer]
+        out = torch.empty(n, d, dtype=torch.float32, device=Xn.device) if want_out else None
+        mm = None
+        for s in range(0, n, self.rows_cap):
+            e = min(n, s + self.rows_cap)
+            chunk = Xn[s:e]
+            mmc = torch.empty(2, d, dtype=torch.float32, device=Xn.device) if want_minmax else None
+            check(self.lib.dcv_mlp_infer(self.h, _ptr(chunk), e - s, Xn.stride(0), _ptr(tmean), _ptr(tevecs), _ptr(pmean), _ptr(prange),
+                                         _ptr(out[s:e]) if want_out else None, _ptr(mmc), _stream()), "dcv_mlp_infer")
+            if want_minmax:
+                if mm is None:
+                    mm = mmc
+                else:  # merging 2*d extrema of chunks
+                    mm = torch.stack([torch.minimum(mm[0], mmc[0]), torch.maximum(mm[1], mmc[1])])
+        return out, mm

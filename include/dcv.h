@@ -1,0 +1,236 @@
+/*
+ * dcv.h -- C-ABI of libdcv.so, the MI355X (gfx950) engine behind deep_cartograph's CV-fit
+ * hot path (train_colvars: pca / tica / htica / ae / deep_tica, projection, k-means).
+ *
+ * The reference has no FFI for this path: the seam is the Python class set in
+ * deep_cartograph/modules/cv_learning/cv_calculator.py and the functions of
+ * deep_cartograph/modules/statistics/statistics.py.  Each entry point
+ * below names the reference code it replaces (file:line relative to
+ * /root/reference/deep_cartograph).  INTEGRATION.md shows the ctypes stub a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DCV_E* code on failure;
+ *     dcv_last_error() returns a thread-local, NUL-terminated description;
+ *   - pointers named *_d are DEVICE pointers (HIP, current device), *_h are HOST pointers;
+ *     the caller owns every buffer, the library never frees caller memory;
+ *   - matrices are row-major; `ld` is the row stride in ELEMENTS;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is
+ *     enqueued asynchronously on it, functions with *_h outputs synchronise that stream;
+ *   - workspace sizes are queried with the matching *_workspace() call; workspaces are
+ *     plain device memory with no state between calls;
+ *   - one process drives one GPU; multi-GPU runs shard frames over ranks and all-reduce the
+ *     small result buffers documented per call.
+ */
+#ifndef DCV_H
+#define DCV_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCV_OK 0
+#define DCV_EINVAL (-1)  /* bad argument / unsupported shape */
+#define DCV_EHIP (-2)    /* HIP runtime error */
+#define DCV_ENOMEM (-3)  /* workspace too small / allocation failed */
+#define DCV_ESTATE (-4)  /* call order violated */
+
+#define DCV_ABI_VERSION 1
+
+int dcv_abi_version(void);
+const char* dcv_last_error(void);
+/* Number of compute units and bytes of device memory of HIP device `device`. */
+int dcv_device_info(int device, int* n_cu, int64_t* hbm_bytes, char* name, size_t name_len);
+
+/* ---------------------------------------------------------------- column statistics (a1)
+ * Replaces DataFrame.agg(['mean','std','min','max']) in CVCalculator.load_training_data,
+ * cv_calculator.py:294-297.  One pass over X (n x F float32).  `out_d` receives 4*F
+ * float64: [sum | sum of squares | min | max].  Sums combine over shards by addition,
+ * min/max by min/max; mean and std(ddof=1) are finalised on the host
+ * (mean = sum/n, var = (sumsq - n*mean^2)/(n-1)).  Algorithmic traffic: 4*n*F bytes read. */
+size_t dcv_col_stats_workspace(int64_t n, int32_t F);
+int dcv_col_stats(const float* X_d, int64_t n, int32_t F, int64_t ld, double* out_d,
+                  void* ws_d, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- normalisation (a3)
+ * Replaces LinearCalculator.normalize_data, cv_calculator.py:833-835
+ * (data.sub_(mean).div_(range) in float32).  Y may alias X (in place, as the reference). */
+int dcv_normalize(const float* X_d, float* Y_d, int64_t n, int32_t F, int64_t ldx, int64_t ldy,
+                  const float* mean_d, const float* range_d, void* stream);
+
+/* ---------------------------------------------------------------- lagged covariance (a4-a7)
+ * Replaces create_timelagged_dataset + the two torch.einsum("ij,ik,i->jk") of
+ * mlcolvar.core.stats.TICA.compute (call sites cv_calculator.py:2247-2261, 2309-2378) and the
+ * X^T X of sklearn PCA (cv_calculator.py:2204-2207).
+ * Pairs are (i, i+lag), i = 0 .. n_pairs-1; rows 0 .. n_pairs+lag-1 of X must be readable
+ * (the last `lag` rows are the halo a shard borrows from its successor).  With
+ * z = x - shift (shift_d may be NULL = 0), out_d receives 2F + 2F*F float64:
+ *   [ a = sum z_t | b = sum z_lag | A = sum z_t z_t^T | B = sum z_t z_lag^T ]   (raw sums).
+ * All four blocks combine over shards by addition.  lag = 0 computes only a and A (PCA);
+ * B and b are then zero.  FP32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulation over chunks
+ * of <= 16384 rows, chunk partials summed in float64 in a fixed order (deterministic).
+ * Algorithmic work: 4*n_pairs*F^2 flop (2*n*F^2 for lag 0), 4*n*F bytes. */
+size_t dcv_lagged_cov_workspace(int64_t n_pairs, int32_t F, int32_t lag);
+int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int64_t ld, int32_t lag,
+                   const float* shift_d, double* out_d, void* ws_d, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- linear projection (a13, a14)
+ * Replaces LinearCalculator.project_data / normalize_cv, cv_calculator.py:918-991:
+ *   p = ((x - fmean)/frange) @ W ; out = (p - cvmean)/cvrange.
+ * fmean_d/frange_d NULL => input already normalised; cvmean_d/cvrange_d NULL => raw p.
+ * bias_d (d floats or NULL) is added to p before the CV normalisation.
+ * W is F x d row-major (the layout of cv_weights.npy), d <= 16.
+ * minmax_d (2*d float32: per-column min then max of `out`, or NULL) combines over shards by
+ * min/max.  out_d may be NULL when only the extrema are wanted.  HBM-bound:
+ * 4*F + 4*d bytes per frame. */
+size_t dcv_project_linear_workspace(int64_t n, int32_t F, int32_t d);
+int dcv_project_linear(const float* X_d, int64_t n, int32_t F, int64_t ld,
+                       const float* fmean_d, const float* frange_d, const float* W_d, int32_t d,
+                       const float* bias_d, const float* cvmean_d, const float* cvrange_d,
+                       float* out_d, float* minmax_d, void* ws_d, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------- MLP engine (a8-a12, a15)
+ * Replaces mlcolvar.cvs.DeepTICA / AutoEncoderCV + the lightning training loop driven by
+ * NonLinear.train, cv_calculator.py:1456-1553 (models :2471-2492, :2569-2590), and the
+ * whole-tensor forward of NonLinear.project_data / normalize_cv (:1735-1754, :1842-1891).
+ *
+ * A model is a chain of Linear layers over PRE-NORMALISED input (dcv_normalize applies
+ * norm_in once; (x-mean)/range is elementwise, so the result is bit-identical to applying it
+ * inside the model).  Parameters live in one flat float32 device buffer, layer by layer,
+ * weight (out x in, row-major, torch.nn.Linear layout) then bias (out).
+ */
+#define DCV_ACT_NONE 0
+#define DCV_ACT_LEAKY_RELU 1 /* slope 0.01 */
+#define DCV_ACT_RELU 2
+#define DCV_ACT_TANH 3
+#define DCV_ACT_ELU 4
+#define DCV_ACT_SOFTPLUS 5
+#define DCV_MAX_LAYERS 16
+
+#define DCV_MODEL_DEEPTICA 1 /* loss = -sum(eig^2) of the batch TICA of nn(x_t), nn(x_lag) */
+#define DCV_MODEL_AE 2       /* loss = mean(((dec(enc(xn)) - xn) * range)^2) */
+
+typedef struct dcv_mlp_desc {
+    int32_t model;                      /* DCV_MODEL_* */
+    int32_t n_layers;                   /* number of Linear layers (AE: encoder + decoder) */
+    int32_t dims[DCV_MAX_LAYERS + 1];   /* dims[0] = F ... dims[n_layers] */
+    int32_t act[DCV_MAX_LAYERS];        /* activation after each Linear */
+    int32_t latent_layer;               /* AE: index of the Linear whose output is the CV
+                                           (encoder depth); Deep-TICA: n_layers */
+    int32_t lag;                        /* Deep-TICA pair offset in rows */
+    int32_t max_batch;                  /* largest number of samples (pairs / frames) per step */
+    double tica_reg;                    /* Deep-TICA: C0 + reg*I */
+    /* Adam (torch.optim.Adam semantics, cv_calculator.py:1377-1380) */
+    double lr, beta1, beta2, eps, weight_decay;
+} dcv_mlp_desc;
+
+typedef struct dcv_mlp dcv_mlp; /* opaque; owns parameters, optimiser state and workspaces */
+
+int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out);
+void dcv_mlp_destroy(dcv_mlp* m);
+/* Length of the flat parameter buffer.  Every tensor starts on a 16-byte boundary, so the
+ * buffer may hold padding: dcv_mlp_param_offset(m, layer, 0) is the offset (in floats) of the
+ * weight of Linear `layer`, (.., 1) of its bias. */
+int64_t dcv_mlp_num_params(const dcv_mlp* m);
+int64_t dcv_mlp_param_offset(const dcv_mlp* m, int32_t layer, int32_t which);
+/* Flat parameter / gradient buffers (device, float32, dcv_mlp_num_params elements).  The
+ * gradient buffer is what a data-parallel run all-reduces (SUM) between backward and apply. */
+float* dcv_mlp_params(dcv_mlp* m);
+float* dcv_mlp_grads(dcv_mlp* m);
+int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* stream);
+int dcv_mlp_get_params(dcv_mlp* m, float* params_h, void* stream);
+int dcv_mlp_set_lr(dcv_mlp* m, double lr);
+/* AE only: per-feature range of norm_in (device copy is made); needed by the loss. */
+int dcv_mlp_set_feature_range(dcv_mlp* m, const float* range_h, void* stream);
+
+/* One optimisation / evaluation step, split in phases so that a data-parallel caller can
+ * all-reduce between them.  Samples of the batch: idx_d != NULL => sample j uses row
+ * idx_d[j] (int64, device) else row row0 + j; Deep-TICA also reads row + lag.
+ * `global_batch` is the number of samples over ALL ranks (= batch on one GPU).
+ *
+ *   dcv_mlp_forward   forward pass; Deep-TICA: leaves the batch statistics
+ *                     [sum f_t (d) | sum f_lag (d) | sum f_t f_t^T (d*d) | sum f_t f_lag^T (d*d)]
+ *                     as float64 in dcv_mlp_stats() (all-reduce SUM across ranks);
+ *                     AE: leaves [sum of squared errors] there.
+ *   dcv_mlp_backward  loss + gradients of this rank's samples -> dcv_mlp_grads()
+ *                     (already scaled for the global batch; all-reduce SUM across ranks).
+ *                     Appends one record to the metrics log (see dcv_mlp_read_log).
+ *                     train = 0: evaluation only (loss logged, no gradients).
+ *   dcv_mlp_apply     Adam update from dcv_mlp_grads().
+ */
+int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
+                    int32_t batch, void* stream);
+double* dcv_mlp_stats(dcv_mlp* m);
+int32_t dcv_mlp_stats_len(const dcv_mlp* m);
+int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
+                     int32_t batch, int64_t global_batch, int32_t train, void* stream);
+int dcv_mlp_apply(dcv_mlp* m, void* stream);
+/* Convenience for one GPU: forward + backward(train=1) + apply. */
+int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
+                       int32_t batch, void* stream);
+/* Convenience for one GPU: forward + backward(train=0). */
+int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
+                      int32_t batch, void* stream);
+
+/* Metrics log: one record of dcv_mlp_log_width() float64 per backward call since the last
+ * reset, kept on the device (no host sync inside an epoch).  Record layout:
+ *   [loss | batch | Deep-TICA: C0 (d*d) | Ctau symmetrised (d*d) | mean f_t (d)].
+ * The host derives eigenvalues / TICA buffers from C0 and Ctau with the reference's own
+ * cholesky + eigh recipe -- a d x d solve per record. */
+int32_t dcv_mlp_log_width(const dcv_mlp* m);
+int dcv_mlp_reset_log(dcv_mlp* m, int32_t capacity, void* stream);
+int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, int32_t* n_records, void* stream);
+
+/* Whole-matrix inference (project / normalize_cv): y = layers[0..latent_layer)(xn);
+ * Deep-TICA additionally y = (y - tmean) @ tevecs (both d floats / d*d row-major, device,
+ * may be NULL); then out = (y - pmean)/prange when given.  minmax_d as in
+ * dcv_project_linear.  out_d (n x d) may be NULL. */
+int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld,
+                  const float* tmean_d, const float* tevecs_d, const float* pmean_d,
+                  const float* prange_d, float* out_d, float* minmax_d, void* stream);
+
+/* ---------------------------------------------------------------- k-means (a17-a19)
+ * Replaces the Lloyd iterations of sklearn.cluster.KMeans as driven by
+ * statistics.kmeans_clustering, statistics.py:159-197 (algorithm: SURVEY.md Appendix A.8).
+ * One E+M accumulation pass over P (n x d float64, d <= 16, k <= 64); x_i = P_i - offset
+ * when offset_d is given (KMeans.fit centres the data by its mean; centres are then
+ * expressed in that frame):
+ *   label_i = argmin_j (|c_j|^2 - 2 x_i.c_j)   (first minimum wins),
+ *   acc_d   = [sums (k*d) | counts (k) | inertia vs `centers` (1) | labels changed (1)] float64,
+ * all of which combine over shards by addition.  labels_d (int32) is read (previous labels,
+ * for the `changed` count) and overwritten.  HBM-bound: 8*d + 8 bytes per point. */
+size_t dcv_kmeans_workspace(int64_t n, int32_t d, int32_t k);
+int dcv_kmeans_step(const double* P_d, int64_t n, int32_t d, const double* offset_d /* d or NULL */,
+                    const double* centers_d, int32_t k, int32_t* labels_d, double* acc_d, double* mindist_d /* n or NULL */,
+                    void* ws_d, size_t ws_bytes, void* stream);
+
+/* Replaces statistics.find_centroids, statistics.py:370-377: for each of the k centroids the
+ * index of the nearest of ALL n points under np.linalg.norm (ties -> lowest index).
+ * best_d receives k pairs [distance (float64) | row (float64-encoded int64 is avoided:
+ * rows_d int64, dist_d float64)] that combine over shards by lexicographic min. */
+size_t dcv_nearest_rows_workspace(int64_t n, int32_t d, int32_t k);
+int dcv_nearest_rows(const double* P_d, int64_t n, int32_t d, const double* centers_d, int32_t k,
+                     int64_t row_offset, double* dist_d, int64_t* rows_d,
+                     void* ws_d, size_t ws_bytes, void* stream);
+
+/* Replaces TrajClusterWorkflow.assign_closest_cluster, traj_cluster_workflow.py:207-238:
+ * nn_d[i] = index of the training point nearest to supplementary point i (squared
+ * Euclidean distance, ties -> lowest index). */
+int dcv_nearest_point(const double* train_d, int64_t n_train, const double* sup_d, int64_t n_sup,
+                      int32_t d, int64_t* nn_d, void* stream);
+
+/* ---------------------------------------------------------------- building block
+ * C[M,N] = op(A).op(B) on the FP32 MFMA engine that the covariance and MLP kernels are built
+ * from (v_mfma_f32_32x32x2_f32, exact f32 products, f32 accumulation).  mode 0 (NT):
+ * A[M,K] . B[N,K]^T; 1 (NN): A[M,K] . B[K,N]; 2 (TN): A[K,M]^T . B[K,N].  Exposed so that the
+ * parity tests can exercise every operand form / tile shape / ragged edge directly. */
+int dcv_gemm_f32(int32_t mode, const float* A_d, int64_t lda, const float* B_d, int64_t ldb, float* C_d,
+                 int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCV_H */

@@ -1,0 +1,232 @@
+"""Parity of the HIP MLP engine (Deep-TICA / autoencoder steps, training, inference) against
+the torch-CPU autograd oracle.  Run on the GPU box: python -m pytest tests -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import linear as ol
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+
+
+def ar_features(n, F, seed, k_slow=3):
+    """SURVEY.md section 8d generator (small): AR(1) slow modes mixed into F features."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    T = np.array([2000, 700, 250, 90][:k_slow], dtype=np.float64)
+    rho = np.exp(-1.0 / T)
+    z = np.zeros((n, k_slow))
+    eta = rng.standard_normal((n, k_slow))
+    for t in range(1, n):
+        z[t] = rho * z[t - 1] + np.sqrt(1 - rho ** 2) * eta[t]
+    A = rng.standard_normal((F, k_slow)) / np.sqrt(k_slow)
+    X = z @ A.T + 0.5 * rng.standard_normal((n, F))
+    X = X * rng.uniform(0.1, 10, F) + rng.uniform(-5, 5, F)
+    return X.astype(np.float32)
+
+
+def normalized(X):
+    st = ol.feature_stats(X)
+    m, r = ol.prepare_normalization(st, "mean_std")
+    return ol.normalize(X, m, r), m.astype(np.float32), r.astype(np.float32)
+
+
+def linears_of(seq):
+    return [m for m in seq if isinstance(m, torch.nn.Linear)]
+
+
+def push_params(eng, lins):
+    eng.set_linears([(l.weight.detach().numpy(), l.bias.detach().numpy()) for l in lins])
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+@pytest.mark.parametrize("dims,n,lag,batch,gather", [
+    ([54, 16, 8, 2], 164, 1, 131, True),
+    ([54, 16, 8, 2], 164, 1, 100, False),
+    ([256, 128, 64, 4], 6000, 10, 2048, True),
+    ([64, 32, 3], 3000, 5, 777, False),
+    ([40, 5], 1000, 2, 500, True),
+])
+def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather):
+    from deep_cartograph_amd import hip
+
+    X = features[0] if dims[0] == 54 else ar_features(n, dims[0], 11)
+    Xn, _, _ = normalized(X)
+    P = Xn.shape[0] - lag
+    acts = ["leaky_relu"] * (len(dims) - 2) + [None]
+    torch.manual_seed(3)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+    lins = linears_of(ref.nn)
+    push_params(eng, lins)
+    Xd = torch.from_numpy(Xn).cuda()
+    if gather:
+        idx = torch.randperm(P)[:batch].contiguous()
+        kw = dict(idx=idx.cuda())
+    else:
+        idx = torch.arange(7, 7 + batch)
+        kw = dict(row0=7, batch=batch)
+    eng.reset_log(2)
+    eng.forward(Xd, **kw)
+    stats = eng.stats_view().cpu().numpy()
+    eng.backward(Xd, **kw)
+    xt = torch.from_numpy(Xn)
+    loss, _ = ref.step(xt[idx], xt[idx + lag])
+    loss.backward()
+    with torch.no_grad():
+        f_t = ref.forward_nn(xt[idx]).double()
+        f_l = ref.forward_nn(xt[idx + lag]).double()
+    d = dims[-1]
+    np.testing.assert_allclose(stats[:d], f_t.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[2 * d:2 * d + d * d].reshape(d, d), (f_t.T @ f_t).numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(stats[2 * d + d * d:].reshape(d, d), (f_t.T @ f_l).numpy(), rtol=1e-4, atol=1e-4)
+    rec = eng.read_log()[0]
+    assert abs(rec[0] - float(loss)) < 2e-4 * max(1.0, abs(float(loss)))
+    assert rec[1] == batch
+    g = eng.grads_view().cpu().numpy()
+    for l, lin in enumerate(lins):
+        wo, bo = eng.offsets[l]
+        gw = lin.weight.grad.numpy()
+        gb = lin.bias.grad.numpy()
+        # stated tolerance: 1% of the largest gradient entry (fp32 d x d solve inside the oracle)
+        assert rel_err(g[wo:wo + gw.size].reshape(gw.shape), gw) < 1e-2, f"layer {l} weight"
+        assert rel_err(g[bo:bo + gb.size], gb) < 1e-2, f"layer {l} bias"
+    eng.close()
+
+
+def test_deeptica_training_matches_oracle():
+    from deep_cartograph_amd import hip
+
+    n, F, lag, bs = 3000, 32, 5, 256
+    dims, acts = [F, 16, 8, 2], ["leaky_relu", "leaky_relu", None]
+    Xn, _, _ = normalized(ar_features(n, F, 5))
+    P = n - lag
+    gen = torch.manual_seed(44)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    tr, va = onn.split_indices(P, [0.8, 0.2], True, gen)
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=bs, lag=lag, tica_reg=1e-6, lr=1e-3)
+    lins = linears_of(ref.nn)
+    push_params(eng, lins)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    xt = torch.from_numpy(Xn)
+    Xd = xt.cuda()
+    ref_losses = []
+    eng.reset_log(256)
+    for epoch in range(3):
+        for b in onn.batches(tr, bs, False):
+            opt.zero_grad()
+            loss, _ = ref.step(xt[b], xt[b + lag])
+            loss.backward()
+            opt.step()
+            ref_losses.append(float(loss))
+            eng.train_step(Xd, idx=b.cuda())
+    log = eng.read_log()
+    assert log.shape[0] == len(ref_losses)
+    np.testing.assert_allclose(log[:, 0], ref_losses, rtol=2e-3, atol=2e-4)
+    for (w, b), lin in zip(eng.get_linears(), lins):
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=3e-4)
+        np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=3e-4)
+    # validation pass: eval steps log the loss and leave the parameters alone
+    before = eng.get_linears()
+    eng.reset_log(8)
+    for b in onn.batches(va, bs, False):
+        eng.eval_step(Xd, idx=b.cuda())
+    vlog = eng.read_log()
+    ref.eval()
+    with torch.no_grad():
+        vref = [float(ref.step(xt[b], xt[b + lag])[0]) for b in onn.batches(va, bs, False)]
+    np.testing.assert_allclose(vlog[:, 0], vref, rtol=2e-3, atol=2e-4)
+    for (w0, b0), (w1, b1) in zip(before, eng.get_linears()):
+        np.testing.assert_array_equal(w0, w1)
+    # logged C0 / Ctau reproduce the oracle's batch TICA eigenvalues
+    d = 2
+    rec = vlog[-1]
+    C0 = torch.tensor(rec[2:2 + d * d].reshape(d, d))
+    Ct = torch.tensor(rec[2 + d * d:2 + 2 * d * d].reshape(d, d))
+    ev, _ = ol.cholesky_eigh(Ct, C0, 1e-6)
+    with torch.no_grad():
+        b = onn.batches(va, bs, False)[-1]
+        ev_ref, _, _ = onn.batch_tica(ref.forward_nn(xt[b]), ref.forward_nn(xt[b + lag]), 1e-6)
+    np.testing.assert_allclose(ev.numpy(), ev_ref.numpy(), atol=5e-4)
+    eng.close()
+
+
+def test_ae_training_matches_oracle(features):
+    from deep_cartograph_amd import hip
+
+    X = features[0]
+    Xn, m, r = normalized(X)
+    F = 54
+    gen = torch.manual_seed(45)
+    ref = onn.AEModel([F, 16, 8, 2], ["leaky_relu", "leaky_relu", None], None, [2, 4, 8, F], ["leaky_relu", "leaky_relu", None], None, m, r)
+    tr, va = onn.split_indices(164, [0.8, 0.2], True, gen)
+    dims = [F, 16, 8, 2, 4, 8, F]
+    acts = ["leaky_relu", "leaky_relu", None, "leaky_relu", "leaky_relu", None]
+    eng = hip.Mlp("ae", dims, acts, max_batch=64, latent_layer=3, lr=1e-3)
+    lins = linears_of(ref.encoder) + linears_of(ref.decoder)
+    push_params(eng, lins)
+    eng.set_feature_range(r)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-3)
+    xt = torch.from_numpy(X)
+    Xd = torch.from_numpy(Xn).cuda()
+    ref_losses = []
+    eng.reset_log(64)
+    # first step: gradients
+    b0 = onn.batches(tr, 64, False)[0]
+    eng.forward(Xd, idx=b0.cuda())
+    eng.backward(Xd, idx=b0.cuda())
+    loss, _ = ref.step(xt[b0])
+    opt.zero_grad()
+    loss.backward()
+    g = eng.grads_view().cpu().numpy()
+    for l, lin in enumerate(lins):
+        wo, bo = eng.offsets[l]
+        gw = lin.weight.grad.numpy()
+        assert rel_err(g[wo:wo + gw.size].reshape(gw.shape), gw) < 1e-3, f"layer {l}"
+        assert rel_err(g[bo:bo + lin.bias.numel()], lin.bias.grad.numpy()) < 1e-3, f"bias {l}"
+    eng.reset_log(64)
+    for epoch in range(5):
+        for b in onn.batches(tr, 64, False):
+            opt.zero_grad()
+            loss, _ = ref.step(xt[b])
+            loss.backward()
+            opt.step()
+            ref_losses.append(float(loss))
+            eng.train_step(Xd, idx=b.cuda())
+    log = eng.read_log()
+    np.testing.assert_allclose(log[:, 0], ref_losses, rtol=1e-4)
+    for (w, b), lin in zip(eng.get_linears(), lins):
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=1e-4)
+    # encoder inference + min/max
+    ref.eval()
+    with torch.no_grad():
+        Y = ref.forward_cv(xt).numpy()
+    out, mm = eng.infer(Xd, want_minmax=True)
+    np.testing.assert_allclose(out.cpu().numpy(), Y, atol=2e-5)
+    np.testing.assert_allclose(mm.cpu().numpy(), np.stack([Y.min(0), Y.max(0)]), atol=2e-5)
+    eng.close()
+
+
+def test_infer_reproduces_reference_torchscript(features, golden_nn, golden_proj):
+    """a15: the bundled deep_tica model.zip (parameters + buffers) through the HIP engine
+    gives the reference's own outputs."""
+    from deep_cartograph_amd import hip
+
+    X = features[0]
+    g = golden_nn
+    mean = g["deep_tica.buffer.norm_in.mean"]
+    rng = g["deep_tica.buffer.norm_in.range"]
+    Xd = torch.from_numpy(X).cuda()
+    Xn = hip.normalize(Xd, torch.from_numpy(mean).cuda(), torch.from_numpy(rng).cuda())
+    eng = hip.Mlp("deep_tica", [54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], max_batch=100, lag=1)
+    eng.set_linears([(g[f"deep_tica.param.nn.nn.{i}.weight"], g[f"deep_tica.param.nn.nn.{i}.bias"]) for i in (0, 3, 6)])
+    out, _ = eng.infer(Xn, tmean=torch.from_numpy(g["deep_tica.buffer.tica.mean"]).cuda(),
+                       tevecs=torch.from_numpy(g["deep_tica.buffer.tica.evecs"]).cuda(),
+                       pmean=torch.from_numpy(g["deep_tica.buffer.postprocessing.mean"]).cuda(),
+                       prange=torch.from_numpy(g["deep_tica.buffer.postprocessing.range"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), g["deep_tica.output"], atol=2e-5)
+    assert np.mean(ol.csv_round4(out.cpu().numpy()) == golden_proj["deep_tica"]) > 0.97
+    eng.close()

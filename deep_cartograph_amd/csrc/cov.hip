@@ -8,7 +8,7 @@
 
 namespace dcv {
 
-constexpr int64_t kCovChunkRows = 16384;
+constexpr int64_t kCovChunkRows = 4096;
 constexpr size_t kCovMaxSlabBytes = (size_t)2 << 30;
 
 struct CovPlan {

@@ -61,6 +61,9 @@ struct dcv_mlp {
     double lr;
     // bookkeeping of the last forward (backward must match)
     int32_t last_batch;
+    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
+    int prof_level, prof_cap, prof_step;
+    std::vector<hipEvent_t> prof_ev;  // [class][step][2], class = 3*layer + {0 fwd, 1 wgrad, 2 dgrad}
 };
 
 namespace dcv {
@@ -381,6 +384,15 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
+static inline bool prof_on(const dcv_mlp* m, int layer) {
+    return m->prof_level > 0 && m->prof_step < m->prof_cap && (m->prof_level > 1 || layer == 0);
+}
+static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStream_t s) {
+    if (!prof_on(m, layer)) return;
+    const size_t cls = (size_t)3 * layer + kind;
+    (void)hipEventRecord(m->prof_ev[(cls * m->prof_cap + m->prof_step) * 2 + which], s);
+}
+
 static RowMap batch_rows(const dcv_mlp* m, const int64_t* idx, int64_t row0, int batch) {
     if (m->desc.model == DCV_MODEL_DEEPTICA) return RowMap{idx, row0, batch, m->desc.lag};
     return RowMap{idx, row0, 0, 0};
@@ -406,6 +418,7 @@ static void mlp_free(dcv_mlp* m) {
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
     for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); }
+    for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     delete m;
 }
 
@@ -450,6 +463,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->lr = desc->lr;
     m->adam_t = 0;
     m->last_batch = 0;
+    m->prof_level = m->prof_cap = m->prof_step = 0;
     m->layers.resize(L);
     int64_t off = 0;
     int maxdim = 0;
@@ -610,8 +624,10 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
         Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
         Operand B = make_operand(m->params + p.w_off, p.in, p.in);
         EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act};
+        prof_mark(m, l, 0, 0, s);
         int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s);
         if (rc) return rc;
+        prof_mark(m, l, 0, 1, s);
     }
     return DCV_OK;
 }
@@ -697,8 +713,10 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
         Operand A = make_operand(dz_cur, m->ld_dz, p.out);
         Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
         EpiSlab epi{p.slab, p.out, p.in, 1, 0};
+        prof_mark(m, l, 1, 0, s);
         int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
         if (rc) return rc;
+        prof_mark(m, l, 1, 1, s);
         const int bblocks = (int)cdiv(R, kColsumRows);
         hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, p.out, m->ld_dz, p.bpart);
         DCV_CHECK_LAUNCH();
@@ -717,8 +735,10 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
             Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
             Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
             EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act};
+            prof_mark(m, l, 2, 0, s);
             rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s);
             if (rc) return rc;
+            prof_mark(m, l, 2, 1, s);
             float* tmp = dz_cur;
             dz_cur = dz_nxt;
             dz_nxt = tmp;
@@ -726,6 +746,45 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     }
     hipLaunchKernelGGL(reduce_grads_kernel, dim3(256, L), dim3(256), 0, s, ra, m->grads, 1.f);
     DCV_CHECK_LAUNCH();
+    if (m->prof_level > 0 && m->prof_step < m->prof_cap) m->prof_step += 1;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_profile_begin(dcv_mlp* m, int32_t max_steps, int32_t level) {
+    DCV_REQUIRE(m && max_steps >= 1 && (level == 1 || level == 2), "dcv_mlp_profile_begin: bad arguments");
+    const size_t need = (size_t)3 * m->L * max_steps * 2;
+    while (m->prof_ev.size() < need) {
+        hipEvent_t e;
+        DCV_CHECK_HIP(hipEventCreate(&e));
+        m->prof_ev.push_back(e);
+    }
+    m->prof_cap = max_steps;
+    m->prof_step = 0;
+    m->prof_level = level;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h) {
+    DCV_REQUIRE(m && ms_h && counts_h, "dcv_mlp_profile_end: null argument");
+    const int steps = m->prof_step;
+    const int level = m->prof_level;
+    m->prof_level = 0;
+    for (int c = 0; c < 3 * m->L; ++c) {
+        ms_h[c] = 0.0;
+        counts_h[c] = 0;
+        const int layer = c / 3, kind = c % 3;
+        if (level < 2 && layer != 0) continue;
+        if (kind == 2 && layer == 0) continue;  // the first layer has no dgrad
+        for (int i = 0; i < steps; ++i) {
+            hipEvent_t a = m->prof_ev[((size_t)c * m->prof_cap + i) * 2 + 0];
+            hipEvent_t b = m->prof_ev[((size_t)c * m->prof_cap + i) * 2 + 1];
+            DCV_CHECK_HIP(hipEventSynchronize(b));
+            float ms = 0.f;
+            DCV_CHECK_HIP(hipEventElapsedTime(&ms, a, b));
+            ms_h[c] += (double)ms;
+            counts_h[c] += 1;
+        }
+    }
     return DCV_OK;
 }
 

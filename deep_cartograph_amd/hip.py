@@ -348,6 +348,18 @@ class Mlp:
         check(self.lib.dcv_mlp_read_log(self.h, out.ctypes.data, out.shape[0], C.byref(n), _stream()), "dcv_mlp_read_log")
         return out[: n.value].copy()
 
+    # -- per-kernel timing (HIP events on the launch stream)
+    def profile_begin(self, max_steps: int, level: int = 1):
+        check(self.lib.dcv_mlp_profile_begin(self.h, int(max_steps), int(level)), "dcv_mlp_profile_begin")
+
+    def profile_end(self):
+        """{(layer, kind): (total_ms, launches)} with kind in 'fwd' | 'wgrad' | 'dgrad'."""
+        ms = np.zeros(3 * self.L, dtype=np.float64)
+        cnt = np.zeros(3 * self.L, dtype=np.int32)
+        check(self.lib.dcv_mlp_profile_end(self.h, ms.ctypes.data, cnt.ctypes.data), "dcv_mlp_profile_end")
+        kinds = ("fwd", "wgrad", "dgrad")
+        return {(c // 3, kinds[c % 3]): (float(ms[c]), int(cnt[c])) for c in range(3 * self.L) if cnt[c] > 0}
+
     # -- inference
     def infer(self, Xn, *, tmean=None, tevecs=None, pmean=None, prange=None, want_out=True, want_minmax=False):
         """Forward of every row of Xn (chunked to the engine's row capacity).

@@ -71,7 +71,7 @@ int dcv_normalize(const float* X_d, float* Y_d, int64_t n, int32_t F, int64_t ld
  *   [ a = sum z_t | b = sum z_lag | A = sum z_t z_t^T | B = sum z_t z_lag^T ]   (raw sums).
  * All four blocks combine over shards by addition.  lag = 0 computes only a and A (PCA);
  * B and b are then zero.  FP32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulation over chunks
- * of <= 16384 rows, chunk partials summed in float64 in a fixed order (deterministic).
+ * of <= 4096 rows, chunk partials summed in float64 in a fixed order (deterministic).
  * Algorithmic work: 4*n_pairs*F^2 flop (2*n*F^2 for lag 0), 4*n*F bytes. */
 size_t dcv_lagged_cov_workspace(int64_t n_pairs, int32_t F, int32_t lag);
 int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int64_t ld, int32_t lag,
@@ -183,6 +183,14 @@ int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* 
 int32_t dcv_mlp_log_width(const dcv_mlp* m);
 int dcv_mlp_reset_log(dcv_mlp* m, int32_t capacity, void* stream);
 int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, int32_t* n_records, void* stream);
+
+/* Per-kernel timing for the roofline report: while enabled, HIP events are recorded on the
+ * launch stream around the three products of each Linear layer (class = 3*layer + {0 forward,
+ * 1 wgrad, 2 dgrad}; level 1 = first layer only, 2 = every layer) for up to max_steps training
+ * steps.  dcv_mlp_profile_end synchronises, stops profiling and returns the summed
+ * milliseconds and launch counts per class (3*n_layers entries each). */
+int dcv_mlp_profile_begin(dcv_mlp* m, int32_t max_steps, int32_t level);
+int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h);
 
 /* Whole-matrix inference (project / normalize_cv): y = layers[0..latent_layer)(xn);
  * Deep-TICA additionally y = (y - tmean) @ tevecs (both d floats / d*d row-major, device,

@@ -21,7 +21,7 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def features():
     g = load_golden("features_164x54.npz")
-    return g["X"], [str(s) for s in g["names"]]
+    return np.ascontiguousarray(g["X"]), [str(s) for s in g["names"]]
 
 
 @pytest.fixture(scope="session")

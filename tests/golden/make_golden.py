@@ -48,7 +48,7 @@ def main():
     df = read_colvars(os.path.join(DATA, "reference", "compute_features", "virtual_dihedrals.dat"))
     with open(os.path.join(DATA, "reference", "filter_features", "filtered_virtual_dihedrals.txt")) as f:
         feats = f.read().split()
-    X = df[feats].to_numpy(dtype=np.float32)
+    X = np.ascontiguousarray(df[feats].to_numpy(dtype=np.float32))
     assert X.shape == (164, 54), X.shape
     np.savez_compressed(os.path.join(OUT, "features_164x54.npz"), X=X, names=np.array(feats))
 

@@ -93,7 +93,12 @@ def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather):
         gb = lin.bias.grad.numpy()
         # stated tolerance: 1% of the largest gradient entry (fp32 d x d solve inside the oracle)
         assert rel_err(g[wo:wo + gw.size].reshape(gw.shape), gw) < 1e-2, f"layer {l} weight"
-        assert rel_err(g[bo:bo + gb.size], gb) < 1e-2, f"layer {l} bias"
+        if l < len(lins) - 1:
+            assert rel_err(g[bo:bo + gb.size], gb) < 1e-2, f"layer {l} bias"
+        else:
+            # the loss is invariant to a constant shift of the outputs (TICA removes the mean), so
+            # the exact gradient of the last bias is 0: both sides hold rounding noise only
+            assert np.max(np.abs(g[bo:bo + gb.size])) < 1e-5 * max(1.0, np.max(np.abs(gw))), f"layer {l} bias"
     eng.close()
 
 
@@ -126,9 +131,10 @@ def test_deeptica_training_matches_oracle():
     log = eng.read_log()
     assert log.shape[0] == len(ref_losses)
     np.testing.assert_allclose(log[:, 0], ref_losses, rtol=2e-3, atol=2e-4)
-    for (w, b), lin in zip(eng.get_linears(), lins):
+    for l, ((w, b), lin) in enumerate(zip(eng.get_linears(), lins)):
         np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=3e-4)
-        np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=3e-4)
+        if l < len(lins) - 1:  # last bias: zero exact gradient, Adam amplifies rounding noise on both sides
+            np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=3e-4)
     # validation pass: eval steps log the loss and leave the parameters alone
     before = eng.get_linears()
     eng.reset_log(8)

@@ -97,7 +97,7 @@ extern "C" int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int6
     DCV_CHECK_LAUNCH();
 
     const Operand op = make_operand(X_d, ld, F, identity_rows(), shift_d);
-    EpiSlab epi{slab, F, F, p.nb, 0};
+    EpiSlab epi{slab, F, F, p.nb, 0, quad_ok(slab, F)};
     if (p.nb == 2)
         rc = launch_gemm_cfg<kTN, CfgCov, 2, EpiSlab>(op, op, lag, F, F, n_pairs, p.k_chunk, epi, s);
     else

@@ -11,7 +11,7 @@ extern "C" int dcv_gemm_f32(int32_t mode, const float* A_d, int64_t lda, const f
     hipStream_t s = as_stream(stream);
     const Operand A = make_operand(A_d, lda, 0);
     const Operand B = make_operand(B_d, ldb, 0);
-    EpiStore epi{C_d, ldc};
+    EpiStore epi{C_d, ldc, quad_ok(C_d, ldc)};
     switch (mode) {
         case kNT: return launch_gemm<kNT, EpiStore>(A, B, M, N, K, 0, epi, s);
         case kNN: return launch_gemm<kNN, EpiStore>(A, B, M, N, K, 0, epi, s);

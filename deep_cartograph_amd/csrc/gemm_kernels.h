@@ -1,6 +1,7 @@
 // __global__ wrappers, epilogues and launch helpers around the block-tile engine of gemm.h.
 #pragma once
 #include <type_traits>
+#include <stdlib.h>
 #include "gemm.h"
 
 namespace dcv {
@@ -29,43 +30,104 @@ __device__ __forceinline__ float act_grad_from_out(int act, float h) {
 }
 
 // ------------------------------------------------------------------ epilogues
+// The activation switch is hoisted out of the element loops: one uniform branch per workgroup.
+template <int N, class F>
+__device__ __forceinline__ void map_quads(float4 (&v)[N], F f) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        v[q].x = f(v[q].x, 0, q);
+        v[q].y = f(v[q].y, 1, q);
+        v[q].z = f(v[q].z, 2, q);
+        v[q].w = f(v[q].w, 3, q);
+    }
+}
+__device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
 struct EpiStore {  // C = acc
+    static constexpr bool kColSum = false;
+    static constexpr bool kSide = false;
     float* C;
     int64_t ldc;
-    __device__ __forceinline__ void operator()(int, int64_t r, int64_t c, float v) const { C[r * ldc + c] = v; }
+    bool vec;
+    __device__ __forceinline__ float4 colconst(int64_t, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    template <int N>
+    __device__ __forceinline__ void transform(float4 (&)[N], const float4 (&)[1], const float4&) const {}
+    __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
+    __device__ __forceinline__ void one(int, int64_t r, int64_t c, float v) const { C[r * ldc + c] = v; }
 };
 struct EpiBiasAct {  // H = act(acc + bias[col])
+    static constexpr bool kColSum = false;
+    static constexpr bool kSide = false;
     float* C;
     int64_t ldc;
     const float* bias;
     int act;
-    __device__ __forceinline__ void operator()(int, int64_t r, int64_t c, float v) const {
+    bool vec;
+    __device__ __forceinline__ float4 colconst(int64_t c, int nvalid) const {
+        return bias ? load_quad(bias + c, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    template <int N>
+    __device__ __forceinline__ void transform(float4 (&v)[N], const float4 (&)[1], const float4& b) const {
+        switch (act) {
+            case DCV_ACT_LEAKY_RELU: map_quads<N>(v, [&](float x, int c, int) { const float z = x + f4c(b, c); return z > 0.f ? z : 0.01f * z; }); break;
+            case DCV_ACT_RELU: map_quads<N>(v, [&](float x, int c, int) { const float z = x + f4c(b, c); return z > 0.f ? z : 0.f; }); break;
+            case DCV_ACT_NONE: map_quads<N>(v, [&](float x, int c, int) { return x + f4c(b, c); }); break;
+            default: map_quads<N>(v, [&](float x, int c, int) { return act_fwd(act, x + f4c(b, c)); }); break;
+        }
+    }
+    __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
+    __device__ __forceinline__ void one(int, int64_t r, int64_t c, float v) const {
         C[r * ldc + c] = act_fwd(act, v + (bias ? bias[c] : 0.f));
     }
 };
-struct EpiActGrad {  // dZ = acc * act'(H)
+struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> bias-gradient partials
+    static constexpr bool kColSum = true;
+    static constexpr bool kSide = true;
     float* C;
     int64_t ldc;
     const float* H;
     int64_t ldh;
     int act;
-    __device__ __forceinline__ void operator()(int, int64_t r, int64_t c, float v) const {
-        C[r * ldc + c] = v * act_grad_from_out(act, H[r * ldh + c]);
+    float* bpart;  // [tiles_m][n]
+    int64_t n;
+    bool vec;
+    __device__ __forceinline__ float4 colconst(int64_t, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ const float* side_ptr(int64_t r, int64_t c) const { return H + r * ldh + c; }
+    template <int N>
+    __device__ __forceinline__ void transform(float4 (&v)[N], const float4 (&h)[N], const float4&) const {
+        switch (act) {
+            case DCV_ACT_LEAKY_RELU: map_quads<N>(v, [&](float x, int c, int q) { return f4c(h[q], c) > 0.f ? x : 0.01f * x; }); break;
+            case DCV_ACT_RELU: map_quads<N>(v, [&](float x, int c, int q) { return f4c(h[q], c) > 0.f ? x : 0.f; }); break;
+            case DCV_ACT_NONE: break;
+            default: map_quads<N>(v, [&](float x, int c, int q) { return x * act_grad_from_out(act, f4c(h[q], c)); }); break;
+        }
     }
+    __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
+    __device__ __forceinline__ void one(int, int64_t, int64_t, float) const {}
+    __device__ __forceinline__ void colsum(int tile_m, int64_t c, float v) const { bpart[(int64_t)tile_m * n + c] = v; }
 };
 struct EpiSlab {  // split-K partials: slab[z][which][M][N]
+    static constexpr bool kColSum = false;
+    static constexpr bool kSide = false;
     float* slab;
     int64_t M, N;
     int nb;
     int64_t z;
-    __device__ __forceinline__ void operator()(int which, int64_t r, int64_t c, float v) const {
+    bool vec;
+    __device__ __forceinline__ float4 colconst(int64_t, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
+    template <int NN>
+    __device__ __forceinline__ void transform(float4 (&)[NN], const float4 (&)[1], const float4&) const {}
+    __device__ __forceinline__ float* out_ptr(int which, int64_t r, int64_t c) const { return slab + ((z * nb + which) * M + r) * N + c; }
+    __device__ __forceinline__ void one(int which, int64_t r, int64_t c, float v) const {
         slab[((z * nb + which) * M + r) * N + c] = v;
     }
 };
 
+inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
+
 // ------------------------------------------------------------------ kernels
 // grid.x = tiles_m * tiles_n (tile_n fastest), grid.z = k splits (TN only)
-template <int MODE, class Cfg, int NB, class Epi>
+template <int MODE, class Cfg, int NB, bool VEC, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     const int tile = blockIdx.x;
@@ -77,30 +139,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
         k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
         if constexpr (std::is_same<Epi, EpiSlab>::value) epi.z = blockIdx.z;
     }
-    gemm_block<MODE, Cfg, NB, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
+    gemm_block<MODE, Cfg, NB, VEC, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
 }
 
-using CfgBig = TileCfg<2, 2, 2, 2, 32>;      // 128 x 128
+#ifndef DCV_BIGCFG
+#define DCV_BIGCFG TileCfg<2, 2, 2, 2, 32>
+#endif
+using CfgBig = DCV_BIGCFG;  // 128 x 128
 using CfgNarrowN = TileCfg<4, 1, 1, 1, 32>;  // 128 x 32
 using CfgNarrowM = TileCfg<1, 4, 1, 1, 32>;  // 32 x 128
 using CfgCov = TileCfg<2, 2, 2, 2, 16>;      // 128 x 128, two B operands, 48 KiB LDS
 
-template <int MODE, class Cfg, int NB, class Epi>
-static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int64_t M, int64_t N, int64_t K,
-                           int64_t k_chunk, const Epi& epi, hipStream_t s) {
-    GemmDims d;
-    d.M = M;
-    d.N = N;
-    d.K = K;
-    d.k_chunk = k_chunk > 0 ? k_chunk : K;
-    d.tiles_m = (int)cdiv(M, Cfg::TM);
-    d.tiles_n = (int)cdiv(N, Cfg::TN);
-    const int64_t splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
-    const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
-    DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
-                (long long)tiles, (long long)splits);
+template <int MODE, class Cfg, int NB, bool VEC, class Epi>
+static int launch_gemm_vec(const Operand& A, const Operand& B, int64_t lag2, const GemmDims& d, int64_t splits,
+                           const Epi& epi, hipStream_t s) {
     constexpr size_t lds = gemm_lds_bytes<Cfg, NB>();
-    auto kern = gemm_kernel<MODE, Cfg, NB, Epi>;
+    auto kern = gemm_kernel<MODE, Cfg, NB, VEC, Epi>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
@@ -108,18 +162,41 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
+    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)d.tiles_m * d.tiles_n), 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
+}
+
+// tiles_m_out (optional) receives the number of row tiles (= bias partial blocks of EpiActGrad)
+template <int MODE, class Cfg, int NB, class Epi>
+static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int64_t M, int64_t N, int64_t K,
+                           int64_t k_chunk, const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
+    GemmDims d;
+    d.M = M;
+    d.N = N;
+    d.K = K;
+    d.k_chunk = k_chunk > 0 ? k_chunk : K;
+    d.tiles_m = (int)cdiv(M, Cfg::TM);
+    d.tiles_n = (int)cdiv(N, Cfg::TN);
+    if (tiles_m_out) *tiles_m_out = d.tiles_m;
+    const int64_t splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
+    const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
+    DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
+                (long long)tiles, (long long)splits);
+    // 16-byte loads: aligned operands; contraction-contiguous (MMAJOR) operands also need K % 4 == 0
+    constexpr bool A_MM = (MODE == kNT || MODE == kNN), B_MM = (MODE == kNT);
+    const bool vec = A.vec_ok && B.vec_ok && (!A_MM || K % 4 == 0) && (!B_MM || K % 4 == 0) && (MODE != kTN || d.k_chunk % 1 == 0);
+    if (vec) return launch_gemm_vec<MODE, Cfg, NB, true, Epi>(A, B, lag2, d, splits, epi, s);
+    return launch_gemm_vec<MODE, Cfg, NB, false, Epi>(A, B, lag2, d, splits, epi, s);
 }
 
 // Picks the tile shape from the output extents.
 template <int MODE, class Epi>
 static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
-                       const Epi& epi, hipStream_t s) {
-    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowN, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s);
-    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s);
-    return launch_gemm_cfg<MODE, CfgBig, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s);
+                       const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
+    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowN, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    return launch_gemm_cfg<MODE, CfgBig, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
 }
 
 inline Operand make_operand(const float* p, int64_t ld, int64_t inner_extent, const RowMap& rows = RowMap{nullptr, 0, 0, 0},

@@ -98,10 +98,11 @@ struct ReduceArgs {
 };
 
 // grads[w] = sum_s slab[s][w] ; grads[b] = sum_blk bpart[blk][b].  A block covers 64 consecutive
-// elements; its 4 waves take the partials q = wave, wave + 4, ... (coalesced 256-byte reads) and
-// are combined in wave order: float64 accumulation, fixed order, deterministic.
-__global__ __launch_bounds__(256) void reduce_grads_kernel(ReduceArgs a, float* __restrict__ grads, float scale) {
-    __shared__ double s_red[4][64];
+// elements; its 16 waves take the partials q = wave, wave + 16, ... (coalesced 256-byte reads)
+// and are combined in wave order: float64 accumulation, fixed order, deterministic.
+constexpr int kRedWaves = 16;
+__global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs a, float* __restrict__ grads, float scale) {
+    __shared__ double s_red[kRedWaves][64];
     const int l = blockIdx.y;
     const ReduceDesc& d = a.l[l];
     const int64_t total = d.w_count + d.out;
@@ -110,15 +111,20 @@ __global__ __launch_bounds__(256) void reduce_grads_kernel(ReduceArgs a, float* 
         const int64_t i = base + lane;
         double s = 0.0;
         if (i < d.w_count) {
-            for (int q = wave; q < d.splits; q += 4) s += (double)d.slab[(int64_t)q * d.w_count + i];
+            const float* p = d.slab + i;
+#pragma unroll 8
+            for (int q = wave; q < d.splits; q += kRedWaves) s += (double)p[(int64_t)q * d.w_count];
         } else if (i < total) {
-            const int64_t j = i - d.w_count;
-            for (int q = wave; q < d.bblocks; q += 4) s += (double)d.bpart[(int64_t)q * d.out + j];
+            const float* p = d.bpart + (i - d.w_count);
+#pragma unroll 8
+            for (int q = wave; q < d.bblocks; q += kRedWaves) s += (double)p[(int64_t)q * d.out];
         }
         s_red[wave][lane] = s;
         __syncthreads();
         if (wave == 0 && i < total) {
-            const double tot = ((s_red[0][lane] + s_red[1][lane]) + s_red[2][lane]) + s_red[3][lane];
+            double tot = 0.0;
+#pragma unroll
+            for (int w = 0; w < kRedWaves; ++w) tot += s_red[w][lane];
             const float g = (float)(tot * (double)scale);
             if (i < d.w_count) grads[d.w_off + i] = g;
             else grads[d.b_off + (i - d.w_count)] = g;
@@ -195,102 +201,167 @@ __global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restri
 }
 
 // One thread: C0, Ctau, loss = -tr((A Ctau)^2) with A = (C0 + reg I)^-1, and the matrices that
-// turn (f_t - mu, f_lag - mu) into dL/df (see DESIGN.md "Deep-TICA gradient").
-__global__ void tica_grad_kernel(const double* __restrict__ stats, int d, double Bg, double reg, float* __restrict__ gradp,
+// turn (f_t - mu, f_lag - mu) into dL/df (see DESIGN.md "Deep-TICA gradient").  DT > 0 fixes the
+// dimension at compile time (everything in registers); DT == 0 is the generic d <= 16 form.
+template <int DT>
+__global__ void tica_grad_kernel(const double* __restrict__ stats, int d_rt, double Bg, double reg, float* __restrict__ gradp,
                                  double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double mu[kMaxTicaDim], ml[kMaxTicaDim];
-    double C0[kMaxTicaDim * kMaxTicaDim], Ct[kMaxTicaDim * kMaxTicaDim], A[kMaxTicaDim * kMaxTicaDim];
-    double K[kMaxTicaDim * kMaxTicaDim], T[kMaxTicaDim * kMaxTicaDim], Lc[kMaxTicaDim * kMaxTicaDim];
+    constexpr int DM = DT > 0 ? DT : kMaxTicaDim;
+    const int d = DT > 0 ? DT : d_rt;
+    double mu[DM], ml[DM];
+    double C0[DM * DM], Ct[DM * DM], A[DM * DM], K[DM * DM], T[DM * DM], Lc[DM * DM];
     const double* sft = stats;
     const double* sfl = stats + d;
     const double* Stt = stats + 2 * d;
     const double* Stl = stats + 2 * d + d * d;
-    for (int i = 0; i < d; ++i) {
-        mu[i] = sft[i] / Bg;
-        ml[i] = sfl[i] / Bg;
-    }
-    for (int i = 0; i < d; ++i)
-        for (int j = 0; j < d; ++j) {
-            C0[i * d + j] = 0.5 * (Stt[i * d + j] + Stt[j * d + i]) / Bg - mu[i] * mu[j];
-            const double cij = Stl[i * d + j] / Bg - mu[i] * ml[j];
-            const double cji = Stl[j * d + i] / Bg - mu[j] * ml[i];
-            Ct[i * d + j] = 0.5 * (cij + cji);
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+        if (i < d) {
+            mu[i] = sft[i] / Bg;
+            ml[i] = sfl[i] / Bg;
         }
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j)
+            if (i < d && j < d) {
+                C0[i * DM + j] = 0.5 * (Stt[i * d + j] + Stt[j * d + i]) / Bg - mu[i] * mu[j];
+                const double cij = Stl[i * d + j] / Bg - mu[i] * ml[j];
+                const double cji = Stl[j * d + i] / Bg - mu[j] * ml[i];
+                Ct[i * DM + j] = 0.5 * (cij + cji);
+            }
     // Cholesky of C0 + reg I
     bool ok = true;
-    for (int i = 0; i < d; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double s = C0[i * d + j] + (i == j ? reg : 0.0);
-            for (int k = 0; k < j; ++k) s -= Lc[i * d + k] * Lc[j * d + k];
-            if (i == j) {
-                if (!(s > 0.0)) ok = false;
-                Lc[i * d + i] = sqrt(s);
-            } else {
-                Lc[i * d + j] = s / Lc[j * d + j];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j)
+            if (i < d && j <= i) {
+                double s = C0[i * DM + j] + (i == j ? reg : 0.0);
+#pragma unroll
+                for (int k = 0; k < DM; ++k)
+                    if (k < j) s -= Lc[i * DM + k] * Lc[j * DM + k];
+                if (i == j) {
+                    if (!(s > 0.0)) ok = false;
+                    Lc[i * DM + i] = sqrt(s);
+                } else {
+                    Lc[i * DM + j] = s / Lc[j * DM + j];
+                }
+            }
+    // A = (L L^T)^-1 : solve L Y = I, then L^T A = Y
+#pragma unroll
+    for (int c = 0; c < DM; ++c)
+        if (c < d) {
+            double y[DM];
+#pragma unroll
+            for (int i = 0; i < DM; ++i)
+                if (i < d) {
+                    double s = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int k = 0; k < DM; ++k)
+                        if (k < i) s -= Lc[i * DM + k] * y[k];
+                    y[i] = s / Lc[i * DM + i];
+                }
+#pragma unroll
+            for (int ii = 0; ii < DM; ++ii) {
+                const int i = DM - 1 - ii;
+                if (i < d) {
+                    double s = y[i];
+#pragma unroll
+                    for (int k = 0; k < DM; ++k)
+                        if (k > i && k < d) s -= Lc[k * DM + i] * A[k * DM + c];
+                    A[i * DM + c] = s / Lc[i * DM + i];
+                }
             }
         }
-    // A = (L L^T)^-1 : solve L Y = I, then L^T A = Y
-    for (int c = 0; c < d; ++c) {
-        double y[kMaxTicaDim];
-        for (int i = 0; i < d; ++i) {
-            double s = (i == c) ? 1.0 : 0.0;
-            for (int k = 0; k < i; ++k) s -= Lc[i * d + k] * y[k];
-            y[i] = s / Lc[i * d + i];
-        }
-        for (int i = d - 1; i >= 0; --i) {
-            double s = y[i];
-            for (int k = i + 1; k < d; ++k) s -= Lc[k * d + i] * A[k * d + c];
-            A[i * d + c] = s / Lc[i * d + i];
-        }
-    }
     // K = A Ct ; loss = -tr(K K)
-    for (int i = 0; i < d; ++i)
-        for (int j = 0; j < d; ++j) {
-            double s = 0.0;
-            for (int k = 0; k < d; ++k) s += A[i * d + k] * Ct[k * d + j];
-            K[i * d + j] = s;
-        }
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j)
+            if (i < d && j < d) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < DM; ++k)
+                    if (k < d) s += A[i * DM + k] * Ct[k * DM + j];
+                K[i * DM + j] = s;
+            }
     double loss = 0.0;
-    for (int i = 0; i < d; ++i)
-        for (int j = 0; j < d; ++j) loss -= K[i * d + j] * K[j * d + i];
+#pragma unroll
+    for (int i = 0; i < DM; ++i)
+#pragma unroll
+        for (int j = 0; j < DM; ++j)
+            if (i < d && j < d) loss -= K[i * DM + j] * K[j * DM + i];
     if (!ok) loss = NAN;
     if (gradp) {
         // T = K A  (= A Ct A, symmetric) ; Gtau = -2 T ; G0 = 2 K T
-        for (int i = 0; i < d; ++i)
-            for (int j = 0; j < d; ++j) {
-                double s = 0.0;
-                for (int k = 0; k < d; ++k) s += K[i * d + k] * A[k * d + j];
-                T[i * d + j] = s;
-            }
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int j = 0; j < DM; ++j)
+                if (i < d && j < d) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < DM; ++k)
+                        if (k < d) s += K[i * DM + k] * A[k * DM + j];
+                    T[i * DM + j] = s;
+                }
         float* g_mu = gradp;
         float* g_u = gradp + d;
         float* g_v = g_u + d * d;
         float* g_c = g_v + d * d;
-        for (int i = 0; i < d; ++i) g_mu[i] = (float)mu[i];
-        for (int i = 0; i < d; ++i) {
-            double cs = 0.0;
-            for (int j = 0; j < d; ++j) {
-                double g0 = 0.0;
-                for (int k = 0; k < d; ++k) g0 += K[i * d + k] * T[k * d + j];
-                const double Gt = -2.0 * 0.5 * (T[i * d + j] + T[j * d + i]);
-                g_u[i * d + j] = (float)(2.0 * (2.0 * g0) / Bg);  // (2/B) G0, G0 = 2 K T
-                g_v[i * d + j] = (float)(Gt / Bg);                // (1/B) Gtau
-                cs += Gt * (ml[j] - mu[j]);
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+            if (i < d) {
+                g_mu[i] = (float)mu[i];
+                double cs = 0.0;
+#pragma unroll
+                for (int j = 0; j < DM; ++j)
+                    if (j < d) {
+                        double g0 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < DM; ++k)
+                            if (k < d) g0 += K[i * DM + k] * T[k * DM + j];
+                        const double Gt = -(T[i * DM + j] + T[j * DM + i]);  // -2 * sym(T)
+                        g_u[i * d + j] = (float)(4.0 * g0 / Bg);              // (2/B) G0, G0 = 2 K T
+                        g_v[i * d + j] = (float)(Gt / Bg);                    // (1/B) Gtau
+                        cs += Gt * (ml[j] - mu[j]);
+                    }
+                g_c[i] = (float)(-cs / Bg);
             }
-            g_c[i] = (float)(-cs / Bg);
-        }
     }
     const int slot = *log_count;
     if (slot < log_cap) {
         double* rec = log + (int64_t)slot * log_width;
         rec[0] = loss;
         rec[1] = Bg;
-        for (int i = 0; i < d * d; ++i) rec[2 + i] = C0[i];
-        for (int i = 0; i < d * d; ++i) rec[2 + d * d + i] = Ct[i];
-        for (int i = 0; i < d; ++i) rec[2 + 2 * d * d + i] = mu[i];
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+#pragma unroll
+            for (int j = 0; j < DM; ++j)
+                if (i < d && j < d) {
+                    rec[2 + i * d + j] = C0[i * DM + j];
+                    rec[2 + d * d + i * d + j] = Ct[i * DM + j];
+                }
+#pragma unroll
+        for (int i = 0; i < DM; ++i)
+            if (i < d) rec[2 + 2 * d * d + i] = mu[i];
     }
     *log_count = slot + 1;
+}
+
+typedef void (*TicaGradFn)(const double*, int, double, double, float*, double*, int*, int, int);
+static TicaGradFn tica_grad_fn(int d) {
+    switch (d) {
+        case 1: return tica_grad_kernel<1>;
+        case 2: return tica_grad_kernel<2>;
+        case 3: return tica_grad_kernel<3>;
+        case 4: return tica_grad_kernel<4>;
+        case 5: return tica_grad_kernel<5>;
+        case 6: return tica_grad_kernel<6>;
+        default: return tica_grad_kernel<0>;
+    }
 }
 
 // dZ_last rows: t rows get Gu u + Gv v + c, lag rows get Gv u  (then * act'(F) of the last layer)
@@ -623,7 +694,7 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
         LayerPlan& p = m->layers[l];
         Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
         Operand B = make_operand(m->params + p.w_off, p.in, p.in);
-        EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act};
+        EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act, quad_ok(p.H, p.ldh) && quad_ok(m->params + p.b_off, 4)};
         prof_mark(m, l, 0, 0, s);
         int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s);
         if (rc) return rc;
@@ -678,7 +749,7 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     float* dz_cur = m->dZ[0];
     float* dz_nxt = m->dZ[1];
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
-        hipLaunchKernelGGL(tica_grad_kernel, dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
+        hipLaunchKernelGGL(tica_grad_fn(m->d_out), dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
                            train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
         DCV_CHECK_LAUNCH();
         if (!train) return DCV_OK;
@@ -700,6 +771,11 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     }
     ReduceArgs ra;
     ra.L = L;
+    // bias-gradient partials of the last layer come from a column-sum pass over dZ_last; those of
+    // every other layer fall out of the dgrad epilogue that produces its dZ
+    int bblocks = (int)cdiv(R, kColsumRows);
+    hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, last.out, m->ld_dz, m->layers[L - 1].bpart);
+    DCV_CHECK_LAUNCH();
     for (int l = L - 1; l >= 0; --l) {
         LayerPlan& p = m->layers[l];
         // wgrad: dW = dZ^T In  (M = out, N = in, K = rows)
@@ -712,14 +788,11 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
         }
         Operand A = make_operand(dz_cur, m->ld_dz, p.out);
         Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
-        EpiSlab epi{p.slab, p.out, p.in, 1, 0};
+        EpiSlab epi{p.slab, p.out, p.in, 1, 0, quad_ok(p.slab, p.in)};
         prof_mark(m, l, 1, 0, s);
         int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
         if (rc) return rc;
         prof_mark(m, l, 1, 1, s);
-        const int bblocks = (int)cdiv(R, kColsumRows);
-        hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, p.out, m->ld_dz, p.bpart);
-        DCV_CHECK_LAUNCH();
         ReduceDesc& rd = ra.l[l];
         rd.slab = p.slab;
         rd.bpart = p.bpart;
@@ -731,12 +804,12 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
         rd.bblocks = bblocks;
         if (l > 0) {
             // dgrad: dZ_prev = (dZ W) * act'(H_prev)   (M = rows, N = in, K = out)
-            const LayerPlan& q = m->layers[l - 1];
+            LayerPlan& q = m->layers[l - 1];
             Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
             Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
-            EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act};
+            EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
             prof_mark(m, l, 2, 0, s);
-            rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s);
+            rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks);
             if (rc) return rc;
             prof_mark(m, l, 2, 1, s);
             float* tmp = dz_cur;
@@ -744,7 +817,7 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
             dz_nxt = tmp;
         }
     }
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3(256, L), dim3(256), 0, s, ra, m->grads, 1.f);
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f);
     DCV_CHECK_LAUNCH();
     if (m->prof_level > 0 && m->prof_step < m->prof_cap) m->prof_step += 1;
     return DCV_OK;

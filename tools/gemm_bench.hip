@@ -1,0 +1,110 @@
+// Developer micro-benchmark of the FP32 MFMA block engine on the three dominant products of
+// the Deep-TICA step (not part of the product build):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I deep_cartograph_amd/csrc tools/gemm_bench.hip \
+//         deep_cartograph_amd/csrc/common.hip -o tools/gemm_bench
+#include "gemm_kernels.h"
+#include <vector>
+#include <cstdlib>
+#include <cstring>
+
+using namespace dcv;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+template <class F>
+static double time_ms(F f, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) f();
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) f();
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
+#ifdef DCV_STAMP
+static void dump_stamps(const char* what, int nblk) {
+    std::vector<unsigned long long> h(8 * 8192);
+    CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(dcv::g_stamp), h.size() * 8));
+    if (nblk > 8192) nblk = 8192;
+    double ph[4] = {0, 0, 0, 0};
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int b = 0; b < nblk; ++b) {
+        for (int p = 0; p < 4; ++p) ph[p] += (double)(h[b * 8 + p + 1] - h[b * 8 + p]);
+        if (h[b * 8] < t0) t0 = h[b * 8];
+        if (h[b * 8 + 4] > t1) t1 = h[b * 8 + 4];
+    }
+    printf("   %s stamps (cycles, mean/WG over %d WGs): prologue %.0f  mainloop %.0f  lds-transpose %.0f  store-loop %.0f   | kernel span %.0f\n",
+           what, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, (double)(t1 - t0));
+}
+#else
+static void dump_stamps(const char*, int) {}
+#endif
+
+int main(int argc, char** argv) {
+    const int64_t R = argc > 1 ? atoll(argv[1]) : 131072;
+    const int F = 512, H1 = 256, H2 = 128;
+    float *X, *W1, *Hb, *dZ, *slab, *W2, *H2b, *bpart, *b1;
+    CK(hipMalloc(&X, (size_t)R * F * 4));
+    CK(hipMalloc(&W1, (size_t)H1 * F * 4));
+    CK(hipMalloc(&b1, (size_t)H1 * 4));
+    CK(hipMalloc(&Hb, (size_t)R * H1 * 4));
+    CK(hipMalloc(&dZ, (size_t)R * H1 * 4));
+    CK(hipMalloc(&W2, (size_t)H2 * H1 * 4));
+    CK(hipMalloc(&H2b, (size_t)R * H2 * 4));
+    CK(hipMalloc(&slab, (size_t)256 * H1 * F * 4));
+    CK(hipMalloc(&bpart, (size_t)(R / 32 + 8) * H1 * 4));
+    std::vector<float> h((size_t)R * F);
+    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    CK(hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W1, h.data(), (size_t)H1 * F * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W2, h.data(), (size_t)H2 * H1 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b1, h.data(), (size_t)H1 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dZ, h.data(), (size_t)R * H1 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(H2b, h.data(), (size_t)R * H2 * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(Hb, 0, (size_t)R * H1 * 4));
+    hipStream_t s = 0;
+    const int it = 20;
+    {   // L0 forward: [R,512] x [256,512]^T
+        Operand A = make_operand(X, F, F), B = make_operand(W1, F, F);
+        EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};
+        double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, it);
+        printf("L0 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);
+        dump_stamps("L0 fwd", (int)(R / 128 * 2));
+    }
+    {   // L0 wgrad: dZ[R,256]^T x X[R,512], split
+        Operand A = make_operand(dZ, H1, H1), B = make_operand(X, F, F);
+        for (int64_t kc : {1024, 2048, 4096}) {
+            EpiSlab epi{slab, H1, F, 1, 0, true};
+            double ms = time_ms([&] { launch_gemm<kTN, EpiSlab>(A, B, H1, F, R, kc, epi, s); }, it);
+            printf("L0 wgrad TN kc=%5lld %8.1f us  %6.1f TF\n", (long long)kc, ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);
+        }
+    }
+    {   // L1 forward: [R,256] x [128,256]^T
+        Operand A = make_operand(Hb, H1, H1), B = make_operand(W2, H1, H1);
+        EpiBiasAct epi{H2b, H2, b1, DCV_ACT_LEAKY_RELU, true};
+        double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H2, H1, 0, epi, s); }, it);
+        printf("L1 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H2 * H1 / ms / 1e9);
+        dump_stamps("L1 fwd", (int)(R / 128));
+    }
+    {   // L1 dgrad: dZ2[R,128] x W2[128,256]
+        Operand A = make_operand(H2b, H2, H2), B = make_operand(W2, H1, H1);
+        EpiActGrad epi{dZ, H1, Hb, H1, DCV_ACT_LEAKY_RELU, bpart, H1, true};
+        double ms = time_ms([&] { launch_gemm<kNN, EpiActGrad>(A, B, R, H1, H2, 0, epi, s); }, it);
+        printf("L1 dgrad NN %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H2 * H1 / ms / 1e9);
+        dump_stamps("L1 dgrad", (int)(R / 128 * 2));
+    }
+    {   // L1 wgrad: dZ2[R,128]^T x H1[R,256]
+        Operand A = make_operand(H2b, H2, H2), B = make_operand(Hb, H1, H1);
+        for (int64_t kc : {512, 1024, 2048}) {
+            EpiSlab epi{slab, H2, H1, 1, 0, true};
+            double ms = time_ms([&] { launch_gemm<kTN, EpiSlab>(A, B, H2, H1, R, kc, epi, s); }, it);
+            printf("L1 wgrad TN kc=%5lld %8.1f us  %6.1f TF\n", (long long)kc, ms * 1e3, 2.0 * R * H2 * H1 / ms / 1e9);
+        }
+    }
+    return 0;
+}

@@ -1,0 +1,18 @@
+#!/bin/bash
+# PMC passes over a short bench run: one rocprofv3 invocation per counter set (no trace domains
+# besides --kernel-trace), summarised per kernel by tools/pmc_summary.py; raw CSVs are deleted.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/pmc
+rm -rf $OUT; mkdir -p $OUT
+ARGS="${BENCH_ARGS:---steps 20 --warmup 5 --no-cpu-baseline --frames 2000000}"
+run() { # name counters...
+  name=$1; shift
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python bench.py $ARGS > $OUT/$name.json 2> $OUT/$name.err
+  echo "$name exit $?"
+  python tools/pmc_summary.py $OUT/$name > $OUT/$name.summary.txt 2>&1
+  rm -rf $OUT/$name
+}
+run p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_WAVES
+run p2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU
+run p3 FETCH_SIZE GRBM_GUI_ACTIVE
+run p4 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum

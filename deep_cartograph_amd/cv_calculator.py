@@ -1,0 +1,992 @@
+"""Collective-variable calculators: host-side mirror of the reference's
+deep_cartograph/modules/cv_learning/cv_calculator.py (class tree, method names, argument meaning,
+output files and error behaviour) over the HIP kernels of libdcv.so.
+
+    cv_calculators_map[name](configuration, output_path)
+        .load_training_data(paths, topologies, ref_topology, features_list)
+        .run(dimension) -> DataFrame of the projected training frames (None = fit failed)
+        .project_colvars(...) / .project_data(...)
+    CVCalculator.load(model.zip, output_path)
+
+The frames x features matrix lives on the GPU from load_training_data on; statistics,
+normalisation, covariance, projection and the AE / Deep-TICA training are HIP kernels, the
+F x F (or d x d) eigen-solves run on the host in float64 (linalg.py).  With torch.distributed
+initialised every rank holds a contiguous block of frames and the small result buffers are
+all-reduced (parallel.py).  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import logging
+import os
+import shutil
+from abc import ABC, abstractmethod
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import export, hip, linalg
+from .colvars import load_feature_matrix
+from .common import closest_power_of_two, remove_files, unzip_files, zip_files
+from .parallel import Comm, append_halo, reduce_col_stats, reduce_minmax
+
+logger = logging.getLogger(__name__)
+
+
+def _dev(a, device, dtype=torch.float32) -> torch.Tensor:
+    return torch.as_tensor(np.asarray(a), dtype=dtype).to(device)
+
+
+def _device() -> torch.device:
+    if not torch.cuda.is_available():
+        raise hip.DcvError("deep_cartograph_amd needs an MI355X: torch.cuda.is_available() is False and there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class CVCalculator(ABC):
+    """Base class (reference: cv_calculator.py:23-747)."""
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        self.configuration: Dict = copy.deepcopy(configuration) if configuration is not None else {}
+        self.architecture_config: Dict = self.configuration.get("architecture", {})
+        self.training_reading_settings: Dict = self.configuration.get("input_colvars", {}) or {}
+        self.feats_norm_mode = self.configuration.get("features_normalization", None)
+        self.bias: Dict = self.configuration.get("bias", {})
+        self.ref_topology_path: Optional[str] = None
+        self.training_data: Optional[torch.Tensor] = None      # device, [frames of this rank, F]
+        self.training_data_labels: Optional[np.ndarray] = None
+        self.validation_data: Optional[torch.Tensor] = None
+        self.projection_data_labels: Optional[np.ndarray] = None
+        self.features_ref_labels: List[str] = []
+        self.features_stats: Dict[str, np.ndarray] = {}
+        self.features_norm_mean: Optional[np.ndarray] = None
+        self.features_norm_range: Optional[np.ndarray] = None
+        self.num_features: int = 0
+        self.num_frames_global: int = 0
+        self.cv = None
+        self.cv_dimension: int = self.configuration.get("dimension")
+        self.cv_labels: List[str] = []
+        self.cv_name: str = None
+        self.cv_range: List[Tuple[float, float]] = []
+        self.parent_output_path: str = output_path
+        self.plumed_files: List[str] = []
+        self.temp_model_path: Optional[str] = None
+        self.comm = Comm()
+
+    def __del__(self):
+        try:
+            if self.temp_model_path and os.path.exists(self.temp_model_path):
+                shutil.rmtree(self.temp_model_path)
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ loading a saved model
+    @classmethod
+    def load(cls, model_path: str, output_path: str):
+        """Factory: model.zip -> the right calculator, ready to project (reference :92-149)."""
+        if not os.path.exists(model_path):
+            raise FileNotFoundError(f"Model file not found: {model_path}")
+        temp_model_path = os.path.join(output_path, "model")
+        unzip_files(model_path, output_path)
+        metadata_path = os.path.join(temp_model_path, "metadata.json")
+        cv_name = None
+        if os.path.exists(metadata_path):
+            with open(metadata_path) as f:
+                cv_name = json.load(f).get("cv_name")
+        else:
+            logger.error(f"Metadata file not found in the model: {metadata_path}")
+        if not cv_name:
+            raise ValueError("Could not determine the CV name from the model file.")
+        klass = cv_calculators_map.get(cv_name)
+        if not klass:
+            raise TypeError(f"Unknown CV calculator name: {cv_name}")
+        inst = klass(output_path=output_path)
+        inst._load_from_folder(temp_model_path)
+        inst.temp_model_path = temp_model_path
+        return inst
+
+    def _load_from_folder(self, folder_path: str):
+        with open(os.path.join(folder_path, "metadata.json")) as f:
+            meta = json.load(f)
+        self.cv_dimension = meta.get("cv_dimension")
+        self.cv_name = meta.get("cv_name")
+        self.set_labels()
+        self.model_output_folder = os.path.join(self.parent_output_path, self.cv_name, "model")
+        if os.path.exists(self.model_output_folder):
+            shutil.rmtree(self.model_output_folder)
+        shutil.copytree(folder_path, self.model_output_folder)
+        with open(os.path.join(self.model_output_folder, "features_labels.txt")) as f:
+            self.features_ref_labels = f.read().strip().split("\n")
+        self.num_features = len(self.features_ref_labels)
+        ref = os.path.join(self.model_output_folder, "ref_topology.pdb")
+        self.ref_topology_path = ref if os.path.exists(ref) else None
+
+    def create_output_folders(self):
+        self.output_path = Path(self.parent_output_path) / self.cv_name
+        self.sensitivity_output_folder = self.output_path / "sensitivity_analysis"
+        self.training_output_folder = self.output_path / "training"
+        self.model_output_folder = self.output_path / "model"
+        if self.comm.rank == 0:
+            for p in (self.output_path, self.sensitivity_output_folder, self.training_output_folder, self.model_output_folder):
+                p.mkdir(parents=True, exist_ok=True)
+        self.comm.barrier()
+
+    # ------------------------------------------------------------------ data
+    def _read(self, paths, features_list):
+        s = self.training_reading_settings
+        return load_feature_matrix(paths, features_list, start=s.get("start", 0), stop=s.get("stop"), stride=s.get("stride", 1))
+
+    def load_training_data(self, train_colvars_paths: List[str], train_topology_paths: Optional[List[str]] = None,
+                           ref_topology_path: Optional[str] = None, features_list: Optional[List[str]] = None):
+        """Read the colvars files, keep the matrix on the GPU, compute the feature statistics
+        with the HIP column-statistics kernel (reference :248-300)."""
+        self.ref_topology_path = ref_topology_path
+        if train_topology_paths is not None and self.ref_topology_path is None:
+            self.ref_topology_path = train_topology_paths[0]
+        logger.info("Reading training data from colvars files...")
+        X, names, labels = self._read(train_colvars_paths, features_list)
+        self.set_training_matrix(X, names, labels)
+
+    def set_training_matrix(self, X, feature_names: Optional[List[str]] = None, labels: Optional[np.ndarray] = None):
+        """Entry point for callers that already hold the (shard of the) feature matrix: a float32
+        array / tensor of this rank's frames.  A device tensor is adopted without a copy."""
+        dev = _device()
+        if isinstance(X, torch.Tensor):
+            Xd = X.to(device=dev, dtype=torch.float32)
+        else:
+            Xd = torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev)
+        if Xd.dim() != 2:
+            raise ValueError("feature matrix must be 2-D")
+        self.training_data = Xd.contiguous()
+        n_local, F = self.training_data.shape
+        self.training_data_labels = labels if labels is not None else np.zeros(n_local, dtype=np.int64)
+        self.features_ref_labels = list(feature_names) if feature_names is not None else [f"f{i}" for i in range(F)]
+        self.num_features = F
+        logger.info(f"Number of features: {self.num_features}")
+        raw = reduce_col_stats(hip.col_stats_raw(self.training_data), self.comm)
+        self.num_frames_global = int(round(self.comm.sum_scalar(n_local, device=dev)))
+        self.features_stats = hip.finalize_stats(raw, self.num_frames_global)
+        self.features_norm_mean, self.features_norm_range = self.prepare_normalization()
+
+    def load_validation_data(self, val_colvars_paths: List[str], val_topology_paths: Optional[List[str]] = None,
+                             ref_topology_path: Optional[str] = None, features_list: Optional[List[str]] = None):
+        logger.info("Reading validation data from colvars files...")
+        X, _, _ = self._read(val_colvars_paths, features_list)
+        self.validation_data = torch.from_numpy(X).to(_device())
+
+    def cv_ready(self) -> bool:
+        return self.cv is not None
+
+    def prepare_normalization(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(mean, range) of the chosen mode; |range| < 1e-8 -> 1 (reference :308-363)."""
+        st = self.features_stats
+        mode = self.feats_norm_mode
+        if mode is None:
+            means = np.zeros(len(st["mean"]))
+            ranges = np.ones(len(st["mean"]))
+        elif mode == "mean_std":
+            means, ranges = st["mean"], st["std"]
+        elif mode == "min_max_range1":
+            means, ranges = st["min"], st["max"] - st["min"]
+        elif mode == "min_max_range2":
+            means, ranges = (st["min"] + st["max"]) / 2, (st["max"] - st["min"]) / 2
+        else:
+            logger.error(f"Normalization mode {mode} not recognized. Exiting...")
+            raise ValueError(f"Normalization mode {mode} not recognized.")
+        ranges = np.array(ranges, copy=True)
+        for i in np.where(np.abs(ranges) < 1e-8)[0]:
+            ranges[i] = 1.0
+            logger.warning(f"Range for feature {i} is close to zero. Setting it to 1.0.")
+        return np.asarray(means), ranges
+
+    # ------------------------------------------------------------------ driver
+    def run(self, cv_dimension: Union[int, None] = None) -> Union[pd.DataFrame, None]:
+        """compute_cv -> normalize_cv -> project the training frames -> save_model ->
+        sensitivity_analysis (reference :366-414).  Returns None when the fit failed."""
+        if self.training_data is None:
+            logger.error("Training data not loaded. Cannot compute CV.")
+            return None
+        self.create_output_folders()
+        if cv_dimension:
+            self.cv_dimension = cv_dimension
+        self.compute_cv()
+        self.set_labels()
+        projection_df = None
+        if self.cv is not None:
+            self.normalize_cv()
+            projection = self.project_data(self.training_data, normalize_data=False)
+            if self.comm.rank == 0:
+                self.save_model()
+                self.sensitivity_analysis()
+            self.comm.barrier()
+            projection_df = pd.DataFrame(projection.numpy(), columns=self.cv_labels)
+        return projection_df
+
+    @abstractmethod
+    def compute_cv(self):
+        raise NotImplementedError
+
+    @abstractmethod
+    def save_weights(self, weights_path: str):
+        raise NotImplementedError
+
+    def save_model(self):
+        """Files common to every calculator: metadata.json, features_labels.txt,
+        ref_topology.pdb (reference :436-452)."""
+        with open(os.path.join(self.model_output_folder, "metadata.json"), "w") as f:
+            json.dump({"cv_name": self.cv_name, "cv_dimension": self.cv_dimension}, f)
+        np.savetxt(os.path.join(self.model_output_folder, "features_labels.txt"), self.features_ref_labels, fmt="%s")
+        if self.ref_topology_path is not None and os.path.exists(self.ref_topology_path):
+            shutil.copyfile(self.ref_topology_path, os.path.join(self.model_output_folder, "ref_topology.pdb"))
+
+    @abstractmethod
+    def get_cv_parameters(self) -> Dict:
+        raise NotImplementedError
+
+    @abstractmethod
+    def get_cv_type(self) -> str:
+        raise NotImplementedError
+
+    @abstractmethod
+    def project_data(self, data, normalize_data: bool = True) -> torch.Tensor:
+        raise NotImplementedError
+
+    @abstractmethod
+    def normalize_cv(self):
+        raise NotImplementedError
+
+    def sensitivity_analysis(self):
+        return
+
+    def project_colvars(self, colvars_paths: Union[List[str], str], topology_paths: Union[List[str], str, None] = None
+                        ) -> Union[pd.DataFrame, None]:
+        """Project colvars files with a fitted / loaded CV (reference :478-526).  Unlike the
+        reference a model without reference topology still projects:
+        the files must then carry the training feature names."""
+        if self.ref_topology_path is None:
+            logger.warning("Reference topology not set. Make sure the colvars file matches the training data.")
+        X, _, labels = load_feature_matrix(colvars_paths, self.features_ref_labels)
+        self.projection_data_labels = labels
+        projected = self.project_data(torch.from_numpy(X))
+        return pd.DataFrame(projected.numpy(), columns=self.cv_labels)
+
+    def set_labels(self):
+        self.cv_labels = [f"{cv_components_map[self.cv_name]} {i + 1}" for i in range(self.cv_dimension)]
+
+    def get_labels(self) -> List[str]:
+        return self.cv_labels
+
+    def get_cv_dimension(self) -> int:
+        return self.cv_dimension
+
+    def get_range(self) -> List[Tuple[float, float]]:
+        return self.cv_range
+
+    def write_plumed_files(self, topology: Optional[str], output_folder: str, waypoint_structures=None):
+        """PLUMED input for this CV.  Without a topology the reference returns early
+        (cv_calculator.py:569-571); with one, the CV definition lines are written: COMBINE for
+        linear CVs, PYTORCH_MODEL for neural ones (assembler.py:333-431)."""
+        if topology is None:
+            logger.warning("No topology given: PLUMED files are not written.")
+            return
+        os.makedirs(output_folder, exist_ok=True)
+        path = os.path.join(output_folder, f"plumed_{self.cv_name}.dat")
+        with open(path, "w") as f:
+            f.write(self.plumed_cv_lines())
+        self.plumed_files.append(path)
+
+    def plumed_cv_lines(self) -> str:
+        raise NotImplementedError
+
+
+# ======================================================================================= linear
+class LinearCalculator(CVCalculator):
+    """Linear CVs: weights F x d (reference :749-1047)."""
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.cv: Optional[np.ndarray] = None
+        self.weights_path: Optional[str] = None
+        self.cv_stats: Dict[str, np.ndarray] = {}
+        self.cv_norm_mean: Optional[np.ndarray] = None
+        self.cv_norm_range: Optional[np.ndarray] = None
+
+    def _load_from_folder(self, folder_path: str):
+        super()._load_from_folder(folder_path)
+        f = self.model_output_folder
+        self.cv = np.load(os.path.join(f, "cv_weights.npy"))
+        self.cv_norm_mean = np.load(os.path.join(f, "cv_norm_mean.npy"))
+        self.cv_norm_range = np.load(os.path.join(f, "cv_norm_range.npy"))
+        self.features_norm_mean = np.load(os.path.join(f, "features_norm_mean.npy"))
+        self.features_norm_range = np.load(os.path.join(f, "features_norm_range.npy"))
+
+    def set_training_matrix(self, X, feature_names=None, labels=None):
+        super().set_training_matrix(X, feature_names, labels)
+        # linear models normalise the stored training matrix in place (reference :800-804)
+        dev = self.training_data.device
+        hip.normalize(self.training_data, _dev(self.features_norm_mean, dev), _dev(self.features_norm_range, dev),
+                      out=self.training_data)
+
+    def normalize_data(self, data: torch.Tensor, normalizing_mean, normalizing_range) -> torch.Tensor:
+        """(data - mean) / range in float32 on the GPU (in place, as the reference)."""
+        dev = _device()
+        d = data if data.is_cuda else data.to(dev)
+        return hip.normalize(d, _dev(normalizing_mean, dev), _dev(normalizing_range, dev), out=d)
+
+    def save_weights(self, weights_path: str):
+        np.save(weights_path, self.cv)
+
+    def save_model(self):
+        super().save_model()
+        if self.cv is None:
+            raise ValueError("No Linear CV weights to save. Please compute the CV before saving the model.")
+        f = self.model_output_folder
+        self.save_weights(os.path.join(f, "cv_weights.npy"))
+        if self.cv_norm_mean is None or self.cv_norm_range is None:
+            raise ValueError("CV normalization parameters have not been computed. Cannot save model.")
+        np.save(os.path.join(f, "cv_norm_mean.npy"), self.cv_norm_mean)
+        np.save(os.path.join(f, "cv_norm_range.npy"), self.cv_norm_range)
+        np.save(os.path.join(f, "features_norm_mean.npy"), self.features_norm_mean)
+        np.save(os.path.join(f, "features_norm_range.npy"), self.features_norm_range)
+        model_path = os.path.join(self.output_path, "model.zip")
+        zip_files(model_path, str(f))
+        shutil.rmtree(f)
+        logger.info(f"Model saved to {model_path}")
+
+    def get_cv_parameters(self):
+        return {"cv_name": self.cv_name, "cv_dimension": self.cv_dimension, "features_norm_mode": self.feats_norm_mode,
+                "features_norm_mean": self.features_norm_mean, "features_norm_range": self.features_norm_range,
+                "cv_stats": self.cv_stats, "weights": self.cv}
+
+    def get_cv_type(self) -> str:
+        return "linear"
+
+    def _weights_dev(self, dev):
+        return _dev(np.ascontiguousarray(self.cv, dtype=np.float32), dev)
+
+    def project_data(self, data, normalize_data: bool = True) -> torch.Tensor:
+        """((x - fmean)/frange) @ W, then (. - cv_mean)/cv_range -- one HBM-bound HIP pass
+        (reference :918-972).  Returns a CPU tensor; the caller's data is left untouched."""
+        if self.cv is None:
+            raise ValueError("CV has not been computed. Cannot project data.")
+        if self.cv_norm_mean is None or self.cv_norm_range is None:
+            raise ValueError("CV normalization parameters have not been computed. Cannot normalize projected data.")
+        dev = _device()
+        X = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.asarray(data, dtype=np.float32))
+        X = X.to(device=dev, dtype=torch.float32).contiguous()
+        kw = {}
+        if normalize_data:
+            if self.features_norm_mean is None or self.features_norm_range is None:
+                raise ValueError("Feature normalization parameters have not been computed. Cannot normalize data.")
+            kw = dict(fmean=_dev(self.features_norm_mean, dev), frange=_dev(self.features_norm_range, dev))
+        out, _ = hip.project_linear(X, self._weights_dev(dev), cvmean=_dev(self.cv_norm_mean, dev),
+                                    cvrange=_dev(self.cv_norm_range, dev), **kw)
+        return out.cpu()
+
+    def normalize_cv(self):
+        """min / max of Xn @ W over all training frames -> [-1, 1] (reference :974-991)."""
+        if self.training_data is None:
+            raise ValueError("Training data not loaded. Cannot compute CV statistics for normalization.")
+        _, mm = hip.project_linear(self.training_data, self._weights_dev(self.training_data.device), want_out=False, want_minmax=True)
+        mm = reduce_minmax(mm, self.comm).cpu().numpy()
+        self.cv_stats = {"min": mm[0], "max": mm[1]}
+        self.cv_norm_mean = (mm[1] + mm[0]) / 2
+        self.cv_norm_range = (mm[1] - mm[0]) / 2
+        self.cv_range = [(-1.0, 1.0)] * self.cv_dimension
+
+    def sensitivity_analysis(self):
+        """|W| per feature, ascending, one CSV per CV dimension (reference :993-1047, without
+        the plots and the per-atom mapping, which need matplotlib / MDAnalysis)."""
+        sens = np.abs(self.cv)
+        for i in range(sens.shape[1]):
+            out = Path(self.sensitivity_output_folder) / f"sensitivity_analysis_{i + 1}"
+            out.mkdir(parents=True, exist_ok=True)
+            order = np.argsort(sens[:, i])
+            pd.DataFrame({"sensitivity": sens[order, i]}, index=list(np.array(self.features_ref_labels)[order])).to_csv(
+                out / "sensitivity_analysis.csv")
+
+    # covariance blocks of the (normalised) training matrix, global over ranks
+    def _covariances(self, lag: int):
+        X = self.training_data
+        n_local, F = X.shape
+        dev = X.device
+        # z = xn - shift with shift ~ column mean of xn keeps the fp32 products well conditioned
+        shift = (self.features_stats["mean"].astype(np.float64) - np.asarray(self.features_norm_mean, dtype=np.float64)) / \
+            np.asarray(self.features_norm_range, dtype=np.float64)
+        shift_t = _dev(shift.astype(np.float32), dev) if np.any(np.abs(shift) > 1e-3) else None
+        Xh, n_pairs_local = append_halo(X, lag, self.comm)
+        if n_pairs_local <= 0:
+            raise ValueError("not enough frames for the requested lag time")
+        raw = self.comm.sum_(hip.lagged_cov_raw(Xh, n_pairs_local, lag, shift_t))
+        n_pairs = int(round(self.comm.sum_scalar(n_pairs_local, device=dev)))
+        delta, C0, Ct = hip.covariances_from_raw(raw.cpu().numpy(), n_pairs, F)
+        return delta, C0, Ct, n_pairs
+
+    def plumed_cv_lines(self) -> str:
+        lines = []
+        names = self.features_ref_labels
+        for i in range(self.cv_dimension):
+            coef = self.cv[:, i] / self.features_norm_range
+            lines.append(f"{self.cv_name}_{i}: COMBINE ARG={','.join(names)} COEFFICIENTS={','.join('%.17g' % c for c in coef)} "
+                         f"PARAMETERS={','.join('%.17g' % m for m in self.features_norm_mean)} PERIODIC=NO")
+        return "\n".join(lines) + "\n"
+
+
+class PCACalculator(LinearCalculator):
+    """Principal component analysis (reference :2174-2215): eigenvectors of the covariance of
+    the normalised features, covariance accumulated by the FP32-MFMA kernel."""
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.cv_name = "pca"
+
+    def compute_cv(self):
+        if self.training_data is None:
+            logger.error("No training data available to compute PCA.")
+            return
+        _, C0, _, _ = self._covariances(lag=0)
+        self.cv = linalg.pca_components(C0, self.cv_dimension).astype(np.float32)
+
+
+class TICACalculator(LinearCalculator):
+    """Time-lagged independent component analysis (reference :2217-2267)."""
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.cv_name = "tica"
+        self.tica_eigenvalues: Optional[np.ndarray] = None
+
+    def compute_cv(self):
+        try:
+            _, C0, Ct, _ = self._covariances(lag=int(self.configuration.get("lag_time")))
+            evals, evecs = linalg.tica_eigh(C0, Ct, reg=1e-6, n_eig=min(self.cv_dimension, C0.shape[0]))
+        except Exception as e:  # the reference logs and skips the CV (:2259-2264)
+            logger.error(f"TICA could not be computed. Error message: {e}")
+            return
+        self.tica_eigenvalues = evals
+        self.cv = evecs.astype(np.float32)
+
+
+class HTICACalculator(LinearCalculator):
+    """Hierarchical TICA (reference :2269-2384).  The level-1 covariances are the diagonal blocks
+    of the global C0 / Ctau and the level-2 ones are T^T C0 T, T^T Ctau T with
+    T = block_diag(level-1 eigenvectors): one data pass in total."""
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.cv_name = "htica"
+        self.num_subspaces = self.configuration.get("num_subspaces")
+        self.subspaces_dimension = self.configuration.get("subspaces_dimension")
+
+    def compute_cv(self):
+        F = self.num_features
+        split = F // self.num_subspaces
+        if split == 0:
+            logger.error(f"Number of subspaces {self.num_subspaces} is larger than number of features {F}. Exiting...")
+            return
+        try:
+            _, C0, Ct, _ = self._covariances(lag=int(self.configuration.get("lag_time")))
+            level1 = []
+            for a in range(0, F, split):  # torch.split semantics: last chunk may be narrower
+                b = min(F, a + split)
+                _, ev = linalg.tica_eigh(C0[a:b, a:b], Ct[a:b, a:b], reg=1e-6, n_eig=min(self.subspaces_dimension, b - a))
+                level1.append(ev)
+            T = linalg.block_diag(level1)
+            C0_2 = T.T @ C0 @ T
+            Ct_2 = T.T @ Ct @ T
+            _, ev2 = linalg.tica_eigh(C0_2, Ct_2, reg=1e-6, n_eig=min(self.cv_dimension, T.shape[1]))
+        except Exception as e:
+            logger.error(f"TICA could not be computed. Error message: {e}")
+            return
+        self.cv = (T @ ev2).astype(np.float32)
+
+
+# ======================================================================================= neural
+_OPTIM_DEFAULTS = {"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.0}
+
+
+class NonLinear(CVCalculator):
+    """Neural CVs trained by the HIP MLP engine (reference :1049-1921)."""
+
+    model_kind: str = ""
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.training_config: Dict = self.configuration.get("training", {})
+        g = self.training_config.get("general", {})
+        es = self.training_config.get("early_stopping", {})
+        self.optimizer_config: Dict = self.training_config.get("optimizer", {})
+        self.lr_scheduler = self.training_config.get("lr_scheduler", None)
+        self.model_to_save = self.training_config.get("model_to_save", "best")
+        self.num_tries: int = g.get("num_tries", 10)
+        self.seed: int = g.get("seed", 42)
+        self.training_validation_lengths: List = g.get("lengths", [0.8, 0.2])
+        self.batch_size: int = g.get("batch_size", 32)
+        self.shuffle: bool = g.get("shuffle", True)
+        self.random_split: bool = g.get("random_split", True)
+        self.max_epochs: int = g.get("max_epochs", 100)
+        self.check_val_every_n_epoch: int = g.get("check_val_every_n_epoch", 1)
+        self.save_check_every_n_epoch: int = g.get("save_check_every_n_epoch", 5)
+        self.early_stop_patience: int = es.get("patience", 20)
+        self.early_stop_delta: float = es.get("min_delta", 1e-5)
+        self.encoder_config: Dict = copy.deepcopy(self.architecture_config.get("encoder", {}) or {})
+        dec = self.architecture_config.get("decoder", {})
+        self.decoder_config: Optional[Dict] = copy.deepcopy(dec) if dec is not None else None
+        self.encoder_hidden_layers: List[int] = list(self.encoder_config.get("layers", []))
+        self.decoder_hidden_layers: List[int] = list((self.decoder_config or self.encoder_config).get("layers", []))
+        self.cv_score: Optional[float] = None
+        self.tries: int = 0
+        self.metrics: Optional[Dict[str, list]] = None
+        self.training_metrics_paths: List[str] = []
+        self.weights_path: Optional[str] = None
+        self.engine: Optional[hip.Mlp] = None
+        self.training_normalized: Optional[torch.Tensor] = None  # norm_in applied once (device)
+
+    # ---- configuration -> layer lists (reference :1155-1219)
+    @staticmethod
+    def _layer_options(cfg: Dict, n_hidden: int):
+        act = list(cfg.get("activation", ["leaky_relu"] * n_hidden))
+        drop = list(cfg.get("dropout", [None] * n_hidden))
+        bn = list(cfg.get("batchnorm", [False] * n_hidden))
+        act.append(cfg.get("last_layer_activation", None))
+        drop.append(cfg.get("last_layer_dropout", None))
+        bn.append(cfg.get("last_layer_batchnorm", False))
+        if any(bn):
+            raise NotImplementedError("batch normalisation layers are not implemented by the HIP engine")
+        if any(d not in (None, 0, 0.0) for d in drop):
+            raise NotImplementedError("dropout > 0 is not implemented by the HIP engine")
+        if len(act) != n_hidden + 1:
+            raise ValueError("one activation per hidden layer expected")
+        return act, drop
+
+    def _adam_options(self):
+        name = self.optimizer_config.get("name", "Adam")
+        if name != "Adam":
+            raise NotImplementedError(f"optimizer {name} is not implemented by the HIP engine (Adam only)")
+        if self.lr_scheduler is not None:
+            raise NotImplementedError("learning-rate schedulers are not implemented by the HIP engine")
+        kw = dict(_OPTIM_DEFAULTS)
+        kw.update(self.optimizer_config.get("kwargs", {}) or {})
+        if kw.get("amsgrad"):
+            raise NotImplementedError("amsgrad is not implemented by the HIP engine")
+        return kw
+
+    # ---- data
+    def set_training_matrix(self, X, feature_names=None, labels=None):
+        super().set_training_matrix(X, feature_names, labels)
+        dev = self.training_data.device
+        # norm_in of the model, applied once: (x - mean)/range is elementwise, so the values are
+        # bit-identical to applying it inside the forward pass (reference :1366-1374)
+        self.training_normalized = hip.normalize(self.training_data, _dev(self.features_norm_mean, dev),
+                                                 _dev(self.features_norm_range, dev))
+
+    # ---- model description, implemented by the subclasses
+    def layer_plan(self) -> Tuple[List[int], List[Optional[str]], int]:
+        raise NotImplementedError
+
+    def n_samples_local(self) -> int:
+        raise NotImplementedError
+
+    def lag(self) -> int:
+        return 0
+
+    def check_batch_size(self, n_samples: int) -> int:
+        """batch >= int(n * lengths[0]) -> closest lower power of two (reference :1278-1309)."""
+        n_train = int(n_samples * self.training_validation_lengths[0])
+        logger.info(f"Number of training samples: {n_train}")
+        logger.info(f"Number of validation samples: {n_samples - n_train}")
+        if self.batch_size >= n_train:
+            self.batch_size = closest_power_of_two(n_train)
+            logger.warning(f"The batch size is larger than the number of samples in the training set. "
+                           f"Setting the batch size to the closest power of two: {self.batch_size}")
+        return self.batch_size
+
+    @staticmethod
+    def _split(n: int, lengths, random_split: bool, generator):
+        """DictModule split: fractional lengths = floor + round-robin remainder; random_split uses
+        ONE randperm of the given generator, else consecutive blocks."""
+        sizes = [int(np.floor(n * f)) for f in lengths]
+        for i in range(n - sum(sizes)):
+            sizes[i % len(sizes)] += 1
+        perm = torch.randperm(n, generator=generator) if random_split else None
+        out, off = [], 0
+        for s in sizes:
+            out.append((perm[off:off + s].clone() if perm is not None else (off, s)))
+            off += s
+        return out
+
+    def _batches(self, part, batch_size: int, dev):
+        """DictLoader: consecutive slices of batch_size, last partial batch kept, fresh randperm per
+        epoch when shuffling.  Yields ('idx', tensor) or ('range', row0, count)."""
+        if isinstance(part, tuple):
+            off, n = part
+            if self.shuffle:
+                part = torch.arange(off, off + n)
+            else:
+                return [("range", off + i, min(batch_size, n - i)) for i in range(0, n, batch_size if batch_size > 0 else n)]
+        idx = part
+        if self.shuffle:
+            idx = idx[torch.randperm(len(idx))]
+        bs = batch_size if batch_size > 0 else len(idx)
+        return [("idx", idx[i:i + bs].to(dev)) for i in range(0, len(idx), bs)]
+
+    def _init_linears(self, dims):
+        """torch.nn.Linear default initialisation in construction order, consuming the global
+        RNG exactly as create_model() does."""
+        lins = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
+        return [(l.weight.detach().numpy().copy(), l.bias.detach().numpy().copy()) for l in lins]
+
+    def _step(self, kind, batch, train: bool, global_batch_of):
+        Xn = self.training_normalized
+        kw = dict(idx=batch[1]) if batch[0] == "idx" else dict(row0=batch[1], batch=batch[2])
+        n = int(batch[1].numel()) if batch[0] == "idx" else int(batch[2])
+        if not self.comm.active:
+            (self.engine.train_step if train else self.engine.eval_step)(Xn, **kw)
+            return
+        self.engine.forward(Xn, **kw)
+        self.comm.sum_(self._stats_view)
+        self.engine.backward(Xn, global_batch=global_batch_of(n), train=train, **kw)
+        if train:
+            self.comm.sum_(self._grads_view)
+            self.engine.apply()
+
+    def _records_to_metrics(self, rec: np.ndarray):
+        """(weighted mean loss, weighted mean eigenvalues or None, TICA buffers of the last record)."""
+        w = rec[:, 1]
+        loss = float((rec[:, 0] * w).sum() / w.sum())
+        return loss, None, None
+
+    def train(self) -> bool:
+        """Multi-try training driver (reference :1456-1553): seed + try, split, model init,
+        epochs with validation, early stopping, best / last snapshot; lowest score wins."""
+        dev = self.training_data.device
+        dims, acts, latent = self.layer_plan()
+        opt = self._adam_options()
+        n_local = self.n_samples_local()
+        if self.comm.active:  # identical batch plans on every rank: use the smallest shard size
+            n_local = int(self.comm.min_(torch.tensor([n_local], dtype=torch.int64, device=dev)).item())
+        n_global = n_local * self.comm.world
+        self.check_batch_size(n_global)
+        world = self.comm.world
+        local_bs = max(1, self.batch_size // world) if self.batch_size > 0 else 0
+        best = None
+        for try_num in range(1, self.num_tries + 1):
+            self.tries = try_num
+            try:
+                result = self._train_once(try_num, dims, acts, latent, opt, n_local, local_bs, dev)
+            except NotImplementedError:
+                raise
+            except Exception as e:
+                logger.error(f"Training try {try_num} failed with an exception: {e}")
+                continue
+            if result is None:
+                continue
+            logger.info(f"Try {try_num}/{self.num_tries}: score = {result['score']:.5f}")
+            if best is None or result["score"] < best["score"]:
+                best = result
+                logger.info(f"  -> New best model (try {try_num}).")
+        if best is None:
+            logger.error(f"{cv_names_map[self.cv_name]} did not produce a valid model after {self.num_tries} tries.")
+            return False
+        self.cv = best["state"]
+        self.cv_score = best["score"]
+        self.metrics = best["metrics"]
+        self.engine.set_linears(self.cv["linears"])
+        logger.info(f"Best model score across {self.num_tries} tries: {best['score']:.5f}")
+        return True
+
+    def _train_once(self, try_num, dims, acts, latent, opt, n_local, local_bs, dev):
+        seed = self.seed + try_num
+        import random
+
+        random.seed(seed)
+        np.random.seed(seed % (2 ** 32))
+        gen = torch.manual_seed(seed)           # seed_everything + DictModule(generator=manual_seed(seed))
+        linears = self._init_linears(dims)      # create_model() (no LR scheduler: model first, split second)
+        parts = self._split(n_local, self.training_validation_lengths, self.random_split, gen)
+        parts = [p if isinstance(p, tuple) or self.shuffle else p.to(dev) for p in parts]  # index plans live on the GPU
+        train_part, val_part = parts[0], parts[1]
+        bs = local_bs if local_bs > 0 else max(len(train_part) if not isinstance(train_part, tuple) else train_part[1], 1)
+        if self.engine is not None:
+            self.engine.close()
+        nmax = max(bs, 1)
+        self.engine = hip.Mlp(self.model_kind, dims, acts, max_batch=nmax, lag=self.lag(), latent_layer=latent,
+                              tica_reg=float(self.configuration.get("tica_regularization", 1e-6)), lr=float(opt["lr"]),
+                              betas=tuple(opt["betas"]), eps=float(opt["eps"]), weight_decay=float(opt["weight_decay"]), device=dev)
+        self.engine.set_linears(linears)
+        if self.model_kind == "ae":
+            self.engine.set_feature_range(self.features_norm_range)
+        self._stats_view = self.engine.stats_view()
+        self._grads_view = self.engine.grads_view()
+        world = self.comm.world
+        gb = lambda n: n * world  # equal shards: every rank runs the same batch sizes
+        metrics: Dict[str, list] = {"train_loss": [], "valid_loss": [], "epoch": []}
+        best_score, best_state, last_state, last_score = float("inf"), None, None, None
+        es_best, wait = float("inf"), 0
+        for epoch in range(self.max_epochs):
+            tb = self._batches(train_part, bs, dev)
+            do_val = (epoch + 1) % self.check_val_every_n_epoch == 0
+            vb = self._batches(val_part, bs, dev) if do_val else []
+            self.engine.reset_log(len(tb) + len(vb))
+            for b in tb:
+                self._step(self.model_kind, b, True, gb)
+            for b in vb:
+                self._step(self.model_kind, b, False, gb)
+            rec = self.engine.read_log()   # the only host sync of the epoch
+            if not np.all(np.isfinite(rec[:, 0])):
+                raise FloatingPointError("non-finite loss (ill-conditioned batch covariance?)")
+            train_loss, _, _ = self._records_to_metrics(rec[:len(tb)])
+            if not do_val:
+                continue
+            valid_loss, eig, buffers = self._records_to_metrics(rec[len(tb):])
+            metrics["train_loss"].append(train_loss)
+            metrics["valid_loss"].append(valid_loss)
+            metrics["epoch"].append(epoch)
+            if eig is not None:
+                for i, v in enumerate(eig):
+                    metrics.setdefault(f"valid_eigval_{i + 1}", []).append(float(v))
+            if (epoch + 1) % self.save_check_every_n_epoch == 0:  # ModelCheckpoint(save_top_k=1, save_last=True)
+                state = {"linears": self.engine.get_linears(), "tica": buffers, "dims": dims, "acts": acts, "latent": latent}
+                last_state, last_score = state, valid_loss
+                if valid_loss < best_score:
+                    best_score, best_state = valid_loss, state
+            if valid_loss < es_best - self.early_stop_delta:  # EarlyStopping(monitor=valid_loss, mode=min)
+                es_best, wait = valid_loss, 0
+            else:
+                wait += 1
+                if wait >= self.early_stop_patience:
+                    break
+        if metrics["valid_loss"] and min(metrics["valid_loss"]) > metrics["valid_loss"][0]:
+            logger.warning(f"Try {try_num}: validation loss did not decrease during training.")
+        if self.model_to_save == "best" and best_state is not None:
+            state, score = best_state, best_score
+        elif last_state is not None:
+            state, score = last_state, last_score
+        else:
+            logger.error("Training finished, but no valid model checkpoint was found.")
+            return None
+        if self.cv_name == "deep_tica" and score < -float(self.cv_dimension):
+            logger.warning(f"Deep TICA validation loss ({score:.5f}) is below the theoretical minimum "
+                           f"({-float(self.cv_dimension):.5f}). Try reducing the learning rate or increasing 'tica_regularization'.")
+            return None
+        return {"state": state, "score": score, "metrics": metrics}
+
+    def compute_cv(self):
+        if self.train():
+            if self.comm.rank == 0:
+                self.plot_training_metrics()
+
+    def plot_training_metrics(self):
+        """train_loss / valid_loss / epoch .npy -> training_metrics.zip, model_score.txt,
+        eigenvalues.txt (reference :1658-1733, 2592-2627; no figures)."""
+        if not self.training_config.get("save_loss", True) or self.metrics is None:
+            return
+        paths = []
+        for key in ("train_loss", "valid_loss", "epoch"):
+            p = os.path.join(self.training_output_folder, f"{key}.npy")
+            np.save(p, np.array(self.metrics[key]))
+            paths.append(p)
+        np.savetxt(os.path.join(self.training_output_folder, "model_score.txt"), np.array([self.cv_score]), fmt="%.7g")
+        if "valid_eigval_1" in self.metrics and self.cv_score in self.metrics["valid_loss"]:
+            bi = self.metrics["valid_loss"].index(self.cv_score)
+            ev = [self.metrics[f"valid_eigval_{i + 1}"][bi] for i in range(self.cv_dimension)]
+            np.savetxt(os.path.join(self.training_output_folder, "eigenvalues.txt"), np.array(ev), fmt="%.7g")
+        zip_files(os.path.join(self.training_output_folder, "training_metrics.zip"), *paths)
+        remove_files(*paths)
+
+    # ---- projection
+    def _infer(self, Xn: torch.Tensor, with_post: bool, want_out=True, want_minmax=False):
+        st = self.cv
+        dev = Xn.device
+        kw = {}
+        if st.get("tica") is not None:
+            kw.update(tmean=_dev(st["tica"][0], dev), tevecs=_dev(np.ascontiguousarray(st["tica"][1]), dev))
+        if with_post and st.get("post") is not None:
+            kw.update(pmean=_dev(st["post"][0], dev), prange=_dev(st["post"][1], dev))
+        return self.engine.infer(Xn, want_out=want_out, want_minmax=want_minmax, **kw)
+
+    def normalize_cv(self):
+        """min / max of the raw CV over the training samples -> Normalization(mode='min_max') as
+        postprocessing (reference :1735-1754)."""
+        rows = self.n_samples_local()
+        _, mm = self._infer(self.training_normalized[:rows], with_post=False, want_out=False, want_minmax=True)
+        mm = reduce_minmax(mm, self.comm).cpu().numpy()
+        self.cv["post"] = ((mm[1] + mm[0]) / 2.0, (mm[1] - mm[0]) / 2.0)
+        self.cv_range = [(-1.0, 1.0)] * self.cv_dimension
+
+    def project_data(self, data, normalize_data: bool = True) -> torch.Tensor:
+        """model(x) for every row (reference :1842-1891).  norm_in is part of the model, so
+        `normalize_data` is ignored as in the reference."""
+        if self.cv is None:
+            raise ValueError("No collective variable model to project data.")
+        logger.info(f"Projecting data onto {cv_names_map[self.cv_name]} ...")
+        dev = _device()
+        if data is self.training_data and self.training_normalized is not None:
+            Xn = self.training_normalized
+        else:
+            X = data if isinstance(data, torch.Tensor) else torch.from_numpy(np.asarray(data, dtype=np.float32))
+            X = X.to(device=dev, dtype=torch.float32).contiguous()
+            if self.cv.get("norm_in") is not None:
+                Xn = hip.normalize(X, _dev(self.cv["norm_in"][0], dev), _dev(self.cv["norm_in"][1], dev))
+            else:
+                Xn = X
+        out, _ = self._infer(Xn, with_post=True)
+        return out.cpu()
+
+    # ---- persistence
+    def to_torch_module(self) -> torch.nn.Module:
+        raise NotImplementedError
+
+    def save_weights(self, weights_path: str):
+        export.save_torchscript(self.to_torch_module(), self.num_features, weights_path)
+        self.weights_path = weights_path
+
+    def save_model(self):
+        super().save_model()
+        if self.cv is None:
+            logger.error("No collective variable model to save.")
+            return
+        self.save_weights(os.path.join(self.model_output_folder, "cv_weights.pt"))
+        model_path = os.path.join(self.output_path, "model.zip")
+        zip_files(model_path, str(self.model_output_folder))
+        shutil.rmtree(self.model_output_folder)
+        logger.info(f"Model saved to {model_path}")
+
+    def _load_from_folder(self, folder_path: str):
+        super()._load_from_folder(folder_path)
+        weights_path = os.path.join(self.model_output_folder, "cv_weights.pt")
+        if not os.path.exists(weights_path):
+            raise FileNotFoundError(f"CV model weights not found at {weights_path}")
+        parts = export.read_torchscript(weights_path)
+        self.weights_path = weights_path
+        dims = [parts["linears"][0][0].shape[1]] + [w.shape[0] for w, _ in parts["linears"]]
+        self.cv = {"linears": parts["linears"], "acts": parts["acts"], "dims": dims, "tica": parts["tica"],
+                   "post": parts["postprocessing"], "norm_in": parts["norm_in"], "latent": len(parts["linears"])}
+        # projection only needs the chain up to the CV (the AE file's encoder): a plain Linear chain
+        self.engine = hip.Mlp("deep_tica", dims, parts["acts"], max_batch=32768, lag=0, device=_device())
+        self.engine.set_linears(parts["linears"])
+
+    def get_cv_parameters(self):
+        return {"cv_name": self.cv_name, "cv_dimension": self.cv_dimension, "weights_path": self.weights_path}
+
+    def get_cv_type(self) -> str:
+        return "non-linear"
+
+    def plumed_cv_lines(self) -> str:
+        return f"{self.cv_name}: PYTORCH_MODEL FILE={self.weights_path} ARG={','.join(self.features_ref_labels)}\n"
+
+
+class AECalculator(NonLinear):
+    """Autoencoder CV (reference :2386-2505): encoder [F]+layers+[d], decoder [d]+layers+[F],
+    loss = mean squared reconstruction error in the original feature units."""
+
+    model_kind = "ae"
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.cv_name = "ae"
+
+    def layer_plan(self):
+        enc_act, _ = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        dec_cfg = self.decoder_config if self.decoder_config is not None else self.encoder_config
+        dec_act, _ = self._layer_options(dec_cfg, len(self.decoder_hidden_layers))
+        # the decoder output must cover the range of the normalised features (reference :1188-1207)
+        if self.feats_norm_mode == "min_max_range1" and dec_act[-1] != "custom_sigmoid":
+            raise NotImplementedError("min_max_range1 needs a custom_sigmoid output layer, which the HIP engine does not implement")
+        if self.feats_norm_mode == "min_max_range2" and dec_act[-1] != "tanh":
+            logger.warning("Changing the last decoder activation to 'tanh' (features normalised to [-1, 1]).")
+            dec_act[-1] = "tanh"
+        enc = [self.num_features] + self.encoder_hidden_layers + [self.cv_dimension]
+        dec = [self.cv_dimension] + self.decoder_hidden_layers + [self.num_features]
+        return enc + dec[1:], enc_act + dec_act, len(enc) - 1
+
+    def n_samples_local(self) -> int:
+        return self.training_data.shape[0]
+
+    def _records_to_metrics(self, rec):
+        w = rec[:, 1]
+        return float((rec[:, 0] * w).sum() / w.sum()), None, None
+
+    def to_torch_module(self):
+        st = self.cv
+        L = st["latent"]
+        ne = len(self.encoder_hidden_layers) + 1
+        enc = export.FeedForward(st["linears"][:L], st["acts"][:L], [0.0] * (ne - 1) + [None])
+        dec = export.FeedForward(st["linears"][L:], st["acts"][L:], [0.0] * (len(st["linears"]) - L - 1) + [None])
+        norm = export.Normalization(self.features_norm_mean, self.features_norm_range) if self.feats_norm_mode is not None else None
+        post = export.Normalization(*st["post"]) if st.get("post") is not None else None
+        return export.AutoEncoderCV(norm, enc, dec, post)
+
+    def train(self) -> bool:
+        ok = super().train()
+        if ok:
+            self.cv["norm_in"] = (self.features_norm_mean, self.features_norm_range)
+        return ok
+
+
+class DeepTICACalculator(NonLinear):
+    """Deep-TICA CV (reference :2507-2627): norm_in -> FeedForward -> TICA on time-lagged pairs,
+    loss = -sum(eigenvalues^2) of the batch TICA."""
+
+    model_kind = "deep_tica"
+
+    def __init__(self, configuration: Optional[Dict] = None, output_path: Optional[str] = None):
+        super().__init__(configuration, output_path)
+        self.cv_name = "deep_tica"
+
+    def lag(self) -> int:
+        return int(self.configuration.get("lag_time"))
+
+    def layer_plan(self):
+        act, _ = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        dims = [self.num_features] + self.encoder_hidden_layers + [self.cv_dimension]
+        return dims, act, len(dims) - 1
+
+    def n_samples_local(self) -> int:
+        return self.training_data.shape[0] - self.lag()   # pairs (i, i+lag) inside this rank's block
+
+    def _records_to_metrics(self, rec):
+        d = self.cv_dimension
+        w = rec[:, 1]
+        loss = float((rec[:, 0] * w).sum() / w.sum())
+        reg = float(self.configuration.get("tica_regularization", 1e-6))
+        evs = []
+        buffers = None
+        for r in rec:
+            C0 = r[2:2 + d * d].reshape(d, d)
+            Ct = r[2 + d * d:2 + 2 * d * d].reshape(d, d)
+            ev, evecs = linalg.tica_eigh(C0, Ct, reg=reg)
+            evs.append(ev)
+            buffers = (r[2 + 2 * d * d:2 + 2 * d * d + d].astype(np.float32), evecs.astype(np.float32))
+        eig = (np.array(evs) * w[:, None]).sum(axis=0) / w.sum()
+        return loss, eig, buffers   # buffers: TICA of the LAST batch (SURVEY.md Appendix A.6 ii)
+
+    def to_torch_module(self):
+        st = self.cv
+        nl = len(st["linears"])
+        nn_ = export.FeedForward(st["linears"], st["acts"], [0.0] * (nl - 1) + [None])
+        norm = export.Normalization(self.features_norm_mean, self.features_norm_range) if self.feats_norm_mode is not None else None
+        tica = export.TICA(st["tica"][1], st["tica"][0])
+        post = export.Normalization(*st["post"]) if st.get("post") is not None else None
+        return export.DeepTICA(norm, nn_, tica, post)
+
+    def train(self) -> bool:
+        ok = super().train()
+        if ok:
+            self.cv["norm_in"] = (self.features_norm_mean, self.features_norm_range)
+        return ok
+
+
+cv_calculators_map = {
+    "pca": PCACalculator,
+    "ae": AECalculator,
+    "tica": TICACalculator,
+    "htica": HTICACalculator,
+    "deep_tica": DeepTICACalculator,
+}
+cv_names_map = {"pca": "PCA", "ae": "AE", "tica": "TICA", "htica": "HTICA", "deep_tica": "DeepTICA", "vae": "VAE", "umap": "UMAP"}
+cv_components_map = {"pca": "PC", "ae": "AE", "tica": "TIC", "htica": "HTIC", "deep_tica": "DeepTIC", "vae": "VAE", "umap": "UMAP"}

@@ -1,0 +1,166 @@
+"""TorchScript export / import of the neural CVs with the module tree the reference writes to
+``model/cv_weights.pt``: ``DeepTICA`` = ``norm_in -> nn -> tica ->
+postprocessing``, ``AutoEncoderCV`` = ``norm_in -> encoder -> postprocessing`` (decoder
+parameters present but unused in ``forward``), ``FeedForward.nn`` a ``Sequential`` of
+Linear / activation / Dropout, parameter names ``nn.nn.{i}.weight`` / ``encoder.nn.{i}.weight``.
+PLUMED's ``PYTORCH_MODEL`` consumes the file directly.  torch is export glue here: the numbers
+inside come from the HIP engine."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+_ACT_MODULES = {
+    "relu": lambda: torch.nn.ReLU(True),
+    "elu": lambda: torch.nn.ELU(True),
+    "tanh": lambda: torch.nn.Tanh(),
+    "softplus": lambda: torch.nn.Softplus(),
+    "leaky_relu": lambda: torch.nn.LeakyReLU(),
+}
+_ACT_FROM_NAME = {"ReLU": "relu", "ELU": "elu", "Tanh": "tanh", "Softplus": "softplus", "LeakyReLU": "leaky_relu"}
+
+
+class Normalization(torch.nn.Module):
+    def __init__(self, mean, rng):
+        super().__init__()
+        self.register_buffer("mean", torch.as_tensor(np.asarray(mean), dtype=torch.float32).clone())
+        self.register_buffer("range", torch.as_tensor(np.asarray(rng), dtype=torch.float32).clone())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return x.sub(self.mean.expand_as(x)).div(self.range.expand_as(x))
+
+
+class FeedForward(torch.nn.Module):
+    """Linear [, activation][, Dropout] per layer, in the reference's module order."""
+
+    def __init__(self, linears: Sequence[Tuple[np.ndarray, np.ndarray]], activation: Sequence[Optional[str]],
+                 dropout: Optional[Sequence[Optional[float]]] = None):
+        super().__init__()
+        mods: List[torch.nn.Module] = []
+        for i, (w, b) in enumerate(linears):
+            lin = torch.nn.Linear(w.shape[1], w.shape[0])
+            with torch.no_grad():
+                lin.weight.copy_(torch.as_tensor(w, dtype=torch.float32))
+                lin.bias.copy_(torch.as_tensor(b, dtype=torch.float32))
+            mods.append(lin)
+            act = activation[i]
+            if act not in (None, "linear"):
+                mods.append(_ACT_MODULES[act]())
+            if dropout is not None and dropout[i] is not None:
+                mods.append(torch.nn.Dropout(p=float(dropout[i])))
+        self.nn = torch.nn.Sequential(*mods)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return self.nn(x)
+
+
+class TICA(torch.nn.Module):
+    def __init__(self, evecs, mean):
+        super().__init__()
+        self.register_buffer("evecs", torch.as_tensor(np.asarray(evecs), dtype=torch.float32).clone())
+        self.register_buffer("mean", torch.as_tensor(np.asarray(mean), dtype=torch.float32).clone())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return torch.matmul(x.sub(self.mean), self.evecs)
+
+
+class ReduceEigenvaluesLoss(torch.nn.Module):
+    def forward(self, evals: torch.Tensor) -> torch.Tensor:
+        return -torch.sum(torch.pow(evals, 2))
+
+
+class MSELoss(torch.nn.Module):
+    def forward(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        return (a - b).square().mean()
+
+
+class DeepTICA(torch.nn.Module):
+    def __init__(self, norm_in, nn, tica, postprocessing):
+        super().__init__()
+        self.loss_fn = ReduceEigenvaluesLoss()
+        self.norm_in = norm_in
+        self.nn = nn
+        self.tica = tica
+        self.postprocessing = postprocessing
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.norm_in is not None:
+            x = self.norm_in(x)
+        x = self.tica(self.nn(x))
+        if self.postprocessing is not None:
+            x = self.postprocessing(x)
+        return x
+
+
+class AutoEncoderCV(torch.nn.Module):
+    def __init__(self, norm_in, encoder, decoder, postprocessing):
+        super().__init__()
+        self.loss_fn = MSELoss()
+        self.norm_in = norm_in
+        self.encoder = encoder
+        self.decoder = decoder
+        self.postprocessing = postprocessing
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.norm_in is not None:
+            x = self.norm_in(x)
+        x = self.encoder(x)
+        if self.postprocessing is not None:
+            x = self.postprocessing(x)
+        return x
+
+
+def save_torchscript(model: torch.nn.Module, n_features: int, path: str) -> None:
+    """to_torchscript(method='trace') in eval mode, as NonLinear.save_weights does
+    (cv_calculator.py:1773-1795)."""
+    model.eval()
+    example = torch.zeros(2, n_features, dtype=torch.float32)
+    with torch.no_grad():
+        traced = torch.jit.trace(model, example)
+    traced.save(path)
+
+
+def _sequential_layers(seq) -> Tuple[List[Tuple[np.ndarray, np.ndarray]], List[Optional[str]]]:
+    """(linears, activation per linear) from a scripted Sequential of Linear/act/Dropout."""
+    linears, acts = [], []
+    for child in seq.children():
+        name = getattr(child, "original_name", type(child).__name__)
+        if name == "Linear":
+            linears.append((child.weight.detach().cpu().numpy().copy(), child.bias.detach().cpu().numpy().copy()))
+            acts.append(None)
+        elif name in _ACT_FROM_NAME:
+            acts[-1] = _ACT_FROM_NAME[name]
+        elif name in ("Dropout", "Identity"):
+            continue
+        else:
+            raise ValueError(f"TorchScript layer {name} is not supported by the HIP engine")
+    return linears, acts
+
+
+def read_torchscript(path: str) -> dict:
+    """Decompose a reference-format cv_weights.pt into arrays the HIP engine can run:
+    kind ('deep_tica' | 'ae'), linears, acts, norm_in (mean, range) or None, tica (mean, evecs)
+    or None, postprocessing (mean, range) or None."""
+    m = torch.jit.load(path, map_location="cpu")
+    m.eval()
+    kids = dict(m.named_children())
+    buf = {k: v.detach().cpu().numpy().copy() for k, v in m.named_buffers()}
+
+    def pair(prefix):
+        if f"{prefix}.mean" in buf and f"{prefix}.range" in buf:
+            return buf[f"{prefix}.mean"], buf[f"{prefix}.range"]
+        return None
+
+    out = {"norm_in": pair("norm_in"), "postprocessing": pair("postprocessing"), "tica": None, "module": m}
+    if "nn" in kids and "tica" in kids:
+        out["kind"] = "deep_tica"
+        out["linears"], out["acts"] = _sequential_layers(kids["nn"].nn)
+        out["tica"] = (buf["tica.mean"], buf["tica.evecs"])
+    elif "encoder" in kids:
+        out["kind"] = "ae"
+        out["linears"], out["acts"] = _sequential_layers(kids["encoder"].nn)
+    else:
+        raise ValueError("unrecognised TorchScript CV model (expected a DeepTICA or AutoEncoderCV tree)")
+    return out

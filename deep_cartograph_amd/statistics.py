@@ -1,0 +1,270 @@
+"""Clustering of the projected trajectories: mirror of the reference's
+deep_cartograph/modules/statistics/statistics.py (optimize_clustering :17-110, cluster_data
+:112-157, kmeans_clustering :159-197, find_centroids :337-379).
+
+k-means runs on the GPU: the Lloyd iterations (assignment, per-cluster sums, inertia, changed
+labels) are one HIP pass each over the float64 points, k-means++ seeding and the convergence
+logic follow scikit-learn's KMeans(random_state=0) step by step on the host (SURVEY.md Appendix
+A.8), so the labels equal the reference's.  Hierarchical clustering and HDBSCAN keep delegating
+to scikit-learn, as the scope table says (O(N^2) tree algorithms, out of scope)."""
+from __future__ import annotations
+
+import logging
+import sys
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import pandas as pd
+import torch
+
+from . import hip
+from .parallel import Comm, reduce_nearest
+
+logger = logging.getLogger(__name__)
+
+KMEANS_TOL = 1e-4       # sklearn default
+KMEANS_MAX_ITER = 300   # sklearn default
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise hip.DcvError("deep_cartograph_amd needs an MI355X for k-means: no GPU visible and there is no CPU path")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class _DevicePoints:
+    """Points resident on the GPU (float64, this rank's shard) with their global statistics."""
+
+    def __init__(self, features: np.ndarray, comm: Comm):
+        self.comm = comm
+        self.dev = _device()
+        self.P = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float64)).to(self.dev)
+        self.n_local, self.d = self.P.shape
+        # mean and mean(var) of the data through the k-means kernel itself (k = 1, centre 0):
+        # sums -> mean, inertia -> sum ||x||^2
+        zero = torch.zeros(1, self.d, dtype=torch.float64, device=self.dev)
+        lab = torch.zeros(self.n_local, dtype=torch.int32, device=self.dev)
+        acc, _ = hip.kmeans_step(self.P, zero, lab)
+        acc = comm.sum_(acc).cpu().numpy()
+        self.n = int(round(acc[self.d]))
+        self.mean = acc[: self.d] / self.n
+        self.tol_abs = (acc[self.d + 1] / self.n - float((self.mean ** 2).sum())) / self.d * KMEANS_TOL
+        self.mean_t = torch.from_numpy(self.mean).to(self.dev)
+        self.labels = torch.full((self.n_local,), -1, dtype=torch.int32, device=self.dev)
+
+    def step(self, centers_c: np.ndarray, want_mindist=False):
+        """One E-step + accumulation against centred centres; returns host (sums, counts, inertia, changed)."""
+        k = centers_c.shape[0]
+        c = torch.from_numpy(np.ascontiguousarray(centers_c)).to(self.dev)
+        acc, md = hip.kmeans_step(self.P, c, self.labels, offset=self.mean_t, want_mindist=want_mindist)
+        acc = self.comm.sum_(acc).cpu().numpy()
+        d = self.d
+        return acc[: k * d].reshape(k, d), acc[k * d: k * d + k], float(acc[k * d + k]), int(round(acc[k * d + k + 1])), md
+
+
+def _kmeans_plusplus(pts: _DevicePoints, k: int, rs: np.random.RandomState) -> np.ndarray:
+    """sklearn _kmeans_plusplus (unit weights) on the centred data.  The draws depend on a
+    sequential float64 cumsum + searchsorted, reproduced with the same NumPy calls on the host
+    copy of the closest-distance vector (single-process only)."""
+    if pts.comm.active:
+        raise NotImplementedError("k-means++ seeding over several ranks is not implemented: pass initial_centroids")
+    X = (pts.P - pts.mean_t).cpu().numpy()
+    n = X.shape[0]
+    xsq = (X * X).sum(axis=1)
+
+    def sq_dists(C):
+        dmat = -2.0 * (C @ X.T)
+        dmat += (C * C).sum(axis=1)[:, None]
+        dmat += xsq[None, :]
+        np.maximum(dmat, 0, out=dmat)
+        return dmat
+
+    centers = np.empty((k, X.shape[1]))
+    trials = 2 + int(np.log(k))
+    w = np.ones(n)
+    cid = rs.choice(n, p=w / w.sum())
+    centers[0] = X[cid]
+    closest = sq_dists(centers[0, None])
+    pot = closest @ w
+    for c in range(1, k):
+        rand_vals = rs.uniform(size=trials) * pot
+        cand = np.searchsorted(np.cumsum(w * closest, dtype=np.float64).ravel(), rand_vals)
+        np.clip(cand, None, closest.size - 1, out=cand)
+        dc = sq_dists(X[cand])
+        np.minimum(closest, dc, out=dc)
+        cpot = dc @ w.reshape(-1, 1)
+        best = np.argmin(cpot)
+        pot = cpot[best]
+        closest = dc[best]
+        centers[c] = X[cand[best]]
+    return centers
+
+
+def _lloyd(pts: _DevicePoints, centers_init: np.ndarray):
+    """sklearn _kmeans_single_lloyd: E+M passes until the labels stop changing or the squared
+    centre shift drops below tol; a final E-step when stopped by tolerance; empty clusters are
+    re-seeded with the points farthest from their centres."""
+    k = centers_init.shape[0]
+    centers = centers_init.copy()
+    pts.labels.fill_(-1)
+    strict = False
+    n_iter = 0
+    for it in range(KMEANS_MAX_ITER):
+        n_iter = it + 1
+        sums, counts, _, changed, md = pts.step(centers, want_mindist=False)
+        empty = np.where(counts == 0)[0]
+        if len(empty):
+            if pts.comm.active:
+                raise NotImplementedError("empty-cluster relocation over several ranks is not implemented")
+            _, _, _, _, md = pts.step(centers, want_mindist=True)   # distances to the assigned (old) centres
+            far = torch.topk(md, len(empty)).indices.cpu().numpy()  # farthest first, as argpartition[...][::-1]
+            lab = pts.labels.cpu().numpy()
+            Xc = (pts.P[torch.from_numpy(far).to(pts.dev)] - pts.mean_t).cpu().numpy()
+            for e, f, x in zip(empty, far, Xc):
+                old = lab[f]
+                sums[old] -= x
+                sums[e] = x
+                counts[e] = 1
+                counts[old] -= 1
+        new = sums / counts[:, None]
+        shift_tot = float(((new - centers) ** 2).sum())
+        centers = new
+        if changed == 0:
+            strict = True
+            break
+        if shift_tot <= pts.tol_abs:
+            break
+    if not strict:
+        pts.step(centers)
+    _, _, inertia, _, _ = pts.step(centers)   # inertia (and labels) against the final centres
+    return pts.labels.clone(), inertia, centers, n_iter
+
+
+def _same_clustering(a: torch.Tensor, b: torch.Tensor, k: int) -> bool:
+    pairs = torch.unique(a.to(torch.int64) * k + b.to(torch.int64))
+    return int(pairs.numel()) == int(torch.unique(a).numel()) == int(torch.unique(b).numel())
+
+
+def kmeans_clustering(feature_matrix: np.ndarray, num_clusters: int, n_init: int,
+                      initial_centroids: Optional[np.ndarray] = None, comm: Optional[Comm] = None):
+    """KMeans(n_clusters, random_state=0, init='k-means++' | array, n_init).fit_predict on the
+    GPU.  Returns (labels int32 NumPy of this rank's points, centres k x d float64)."""
+    comm = comm or Comm()
+    pts = _DevicePoints(feature_matrix, comm)
+    rs = np.random.RandomState(0)
+    if initial_centroids is not None:
+        init = np.asarray(initial_centroids, dtype=np.float64) - pts.mean
+        num_clusters, n_init = init.shape[0], 1
+    else:
+        init = None
+    if not (1 <= num_clusters <= 64) or pts.d > 16:
+        raise NotImplementedError(f"the HIP k-means kernel supports k <= 64, d <= 16 (got k={num_clusters}, d={pts.d})")
+    logger.debug(f"Number of clusters: {num_clusters}")
+    best = None
+    for _ in range(n_init):
+        c0 = init if init is not None else _kmeans_plusplus(pts, num_clusters, rs)
+        labels, inertia, centers, n_iter = _lloyd(pts, c0)
+        if best is None or (inertia < best[1] and not _same_clustering(labels, best[0], num_clusters)):
+            best = (labels, inertia, centers, n_iter)
+    labels, inertia, centers, _ = best
+    return labels.cpu().numpy(), centers + pts.mean
+
+
+def cluster_data(features: np.ndarray, settings: Dict, initial_centroids: np.ndarray = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Cluster with the algorithm named in `settings` (defaults filled in place, as the reference
+    does, statistics.py:134-142)."""
+    settings["algorithm"] = settings.get("algorithm", "kmeans")
+    settings["num_clusters"] = settings.get("num_clusters", 10)
+    settings["n_init"] = settings.get("n_init", 10)
+    settings["min_cluster_size"] = settings.get("min_cluster_size", int(0.1 * features.shape[0]))
+    settings["min_samples"] = settings.get("min_samples", max(int(0.001 * features.shape[0]), 1))
+    settings["cluster_selection_epsilon"] = settings.get("cluster_selection_epsilon", 0)
+    settings["linkage"] = settings.get("linkage", "complete")
+    settings["max_cluster_size"] = settings.get("max_cluster_size")
+    settings["cluster_selection_method"] = settings.get("cluster_selection_method", "eom")
+    algo = settings["algorithm"]
+    if algo == "kmeans":
+        return kmeans_clustering(features, settings["num_clusters"], settings["n_init"], initial_centroids)
+    if algo == "hierarchical":
+        from sklearn.cluster import AgglomerativeClustering
+
+        labels = AgglomerativeClustering(n_clusters=settings["num_clusters"], distance_threshold=None,
+                                         linkage=settings["linkage"]).fit_predict(features)
+        cents = np.stack([features[labels == i].mean(axis=0) for i in range(len(np.unique(labels)))])
+        return labels, cents
+    if algo == "hdbscan":
+        from sklearn.cluster import HDBSCAN
+
+        hdb = HDBSCAN(min_cluster_size=settings["min_cluster_size"], min_samples=settings["min_samples"], store_centers="centroid",
+                      cluster_selection_epsilon=settings["cluster_selection_epsilon"], max_cluster_size=settings["max_cluster_size"],
+                      cluster_selection_method=settings["cluster_selection_method"], allow_single_cluster=False)
+        hdb.fit(features)
+        return hdb.labels_, hdb.centroids_
+    raise Exception(f"clustering algorithm {algo} not implemented")
+
+
+def optimize_clustering(features: np.ndarray, settings: Dict):
+    """k in search_interval (inclusive): cluster, Calinski-Harabasz / Davies-Bouldin / silhouette,
+    min-max normalise each list, best (CH - DB + Sil) / 3 (reference :17-110).  The scores stay
+    on scikit-learn (silhouette is O(N^2): SURVEY.md section 8 f4)."""
+    if settings["algorithm"] in ("kmeans", "hierarchical"):
+        from sklearn.metrics import calinski_harabasz_score, davies_bouldin_score, silhouette_score
+
+        lo, hi = settings.get("search_interval", [2, 15])
+        ks = list(range(lo, hi + 1))
+        ch, db, si, results = [], [], [], []
+        for N in ks:
+            settings["num_clusters"] = N
+            labels, centroids = cluster_data(features, settings)
+            ch.append(calinski_harabasz_score(features, labels))
+            db.append(davies_bouldin_score(features, labels))
+            si.append(silhouette_score(features, labels))
+            results.append((labels, centroids))
+        with np.errstate(invalid="ignore", divide="ignore"):
+            ch = (ch - np.min(ch)) / (np.max(ch) - np.min(ch))
+            db = (db - np.min(db)) / (np.max(db) - np.min(db))
+            si = (si - np.min(si)) / (np.max(si) - np.min(si))
+        score = (np.array(ch) - np.array(db) + np.array(si)) / 3
+        best = int(np.argmax(score))
+        logger.info(f"Best number of clusters: {ks[best]}")
+        cluster_labels, centroids = results[best]
+    elif settings["algorithm"] == "hdbscan":
+        cluster_labels, centroids = cluster_data(features, settings)
+    else:
+        raise Exception(f"clustering algorithm {settings['algorithm']} not implemented")
+    if len(centroids) == 0:
+        logger.warning("No clusters found using the provided settings. Try different settings or a different algorithm")
+    return cluster_labels, centroids
+
+
+def find_centroids(data: pd.DataFrame, centroids: np.ndarray, clustering_features: list, comm: Optional[Comm] = None,
+                   row_offset: int = 0) -> pd.DataFrame:
+    """Adds a boolean 'centroid' column marking, for every centroid, the globally nearest sample
+    (np.linalg.norm, first index on ties) -- one HIP pass per centroid (reference :337-379)."""
+    if len(centroids) == 0:
+        logger.warning("No centroids found")
+        return pd.DataFrame()
+    if len(centroids[0]) != len(clustering_features):
+        logger.error("  The dimension of the centroids is not the same as the dimension of the used features for clustering.\n")
+        sys.exit(1)
+    comm = comm or Comm()
+    dev = _device()
+    P = torch.from_numpy(np.ascontiguousarray(data.loc[:, clustering_features].values, dtype=np.float64)).to(dev)
+    C = torch.from_numpy(np.ascontiguousarray(centroids, dtype=np.float64)).to(dev)
+    dist, rows = hip.nearest_rows(P, C, row_offset=row_offset)
+    _, rows = reduce_nearest(dist, rows, comm)
+    data["centroid"] = False
+    for r in rows.cpu().numpy():
+        local = int(r) - row_offset
+        if 0 <= local < len(data):
+            data.at[data.index[local], "centroid"] = True
+    return data
+
+
+def assign_closest_cluster(train_points: np.ndarray, train_labels: np.ndarray, sup_points: np.ndarray) -> np.ndarray:
+    """Label of the nearest training point for each supplementary point
+    (TrajClusterWorkflow.assign_closest_cluster, traj_cluster_workflow.py:207-238)."""
+    dev = _device()
+    nn = hip.nearest_point(torch.from_numpy(np.ascontiguousarray(train_points, dtype=np.float64)).to(dev),
+                           torch.from_numpy(np.ascontiguousarray(sup_points, dtype=np.float64)).to(dev))
+    return np.asarray(train_labels)[nn.cpu().numpy()]

@@ -1,0 +1,300 @@
+"""End-to-end parity of the calculator / clustering mirror on the GPU against the reference's
+golden fixtures and the CPU oracle.  Run on the GPU box: python -m pytest tests -m gpu"""
+import io
+import json
+import os
+import zipfile
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import cluster as oc
+from oracle import linear as ol
+from oracle import nn as onn
+
+pytestmark = pytest.mark.gpu
+
+CVS = ["pca", "tica", "htica", "ae", "deep_tica", "vae"]
+TEST_COMMON = {
+    "dimension": 2, "lag_time": 1, "features_normalization": "mean_std", "num_subspaces": 10, "subspaces_dimension": 5,
+    "tica_regularization": 1e-6,
+    "architecture": {
+        "encoder": {"layers": [16, 8], "activation": ["leaky_relu", "leaky_relu"], "batchnorm": [False, False], "dropout": [0, 0],
+                    "last_layer_activation": None, "last_layer_batchnorm": False, "last_layer_dropout": None},
+        "decoder": {"layers": [4, 8], "activation": ["leaky_relu", "leaky_relu"], "batchnorm": [False, False], "dropout": [0, 0],
+                    "last_layer_activation": None, "last_layer_batchnorm": False, "last_layer_dropout": None}},
+    "training": {"general": {"num_tries": 1, "seed": 42, "lengths": [0.8, 0.2], "batch_size": 256, "max_epochs": 40, "shuffle": False,
+                             "random_split": True, "check_val_every_n_epoch": 1, "save_check_every_n_epoch": 1},
+                 "early_stopping": {"patience": 20, "min_delta": 1e-5}, "optimizer": {"name": "Adam", "kwargs": {"lr": 1e-3, "weight_decay": 0}},
+                 "lr_scheduler": None, "lr_scheduler_config": None, "save_loss": True, "plot_loss": False, "model_to_save": "last"},
+}
+
+
+def make_calc(name, out, **over):
+    from deep_cartograph_amd.cv_calculator import cv_calculators_map
+
+    cfg = json.loads(json.dumps(TEST_COMMON))
+    cfg.update(over)
+    return cv_calculators_map[name](cfg, str(out))
+
+
+def match_fraction(a, b):
+    return float(np.mean(ol.csv_round4(a) == b))
+
+
+def test_pca_golden(features, golden_linear, golden_proj, tmp_path):
+    X, names = features
+    calc = make_calc("pca", tmp_path)
+    calc.set_training_matrix(X.copy(), names)
+    # the kernel accumulates in float64 (pandas in float32): equal to 1 float32 ulp
+    np.testing.assert_allclose(calc.features_norm_mean.astype(np.float32), golden_linear["pca.features_norm_mean"], rtol=4e-7, atol=1.2e-7)
+    np.testing.assert_allclose(calc.features_norm_range, golden_linear["pca.features_norm_range"], rtol=3e-7)
+    df = calc.run(2)
+    assert list(df.columns) == ["PC 1", "PC 2"]
+    np.testing.assert_allclose(calc.cv, golden_linear["pca.cv_weights"], atol=2e-6)
+    np.testing.assert_allclose(calc.cv_norm_mean, golden_linear["pca.cv_norm_mean"], atol=2e-5)
+    np.testing.assert_allclose(df.to_numpy(), golden_proj["pca"], atol=1.5e-4)   # golden has 4 decimals
+    assert match_fraction(df.to_numpy(), golden_proj["pca"]) > 0.97
+    # model.zip: reference layout, loads back and projects raw features identically
+    zpath = tmp_path / "pca" / "model.zip"
+    with zipfile.ZipFile(zpath) as z:
+        assert sorted(z.namelist()) == sorted(["model/metadata.json", "model/features_labels.txt", "model/cv_weights.npy",
+                                               "model/cv_norm_mean.npy", "model/cv_norm_range.npy",
+                                               "model/features_norm_mean.npy", "model/features_norm_range.npy"])
+        assert json.loads(z.read("model/metadata.json")) == {"cv_name": "pca", "cv_dimension": 2}
+    from deep_cartograph_amd.cv_calculator import CVCalculator
+
+    loaded = CVCalculator.load(str(zpath), str(tmp_path / "reload"))
+    out = loaded.project_data(torch.from_numpy(X.copy())).numpy()
+    np.testing.assert_allclose(out, df.to_numpy(), atol=2e-6)
+    assert (tmp_path / "pca" / "sensitivity_analysis" / "sensitivity_analysis_1" / "sensitivity_analysis.csv").exists()
+
+
+def test_reference_model_zips_project_to_goldens(features, golden_linear, golden_proj, tmp_path):
+    """a14/a16: the arrays of the reference's bundled linear model.zip files, written in the
+    reference layout, load through CVCalculator.load and reproduce the golden CSVs."""
+    from deep_cartograph_amd.cv_calculator import CVCalculator
+
+    X, names = features
+    for cv in ("pca", "tica", "htica"):
+        zpath = tmp_path / f"{cv}_model.zip"
+        with zipfile.ZipFile(zpath, "w") as z:
+            z.writestr("model/metadata.json", json.dumps({"cv_name": cv, "cv_dimension": 2}))
+            z.writestr("model/features_labels.txt", "\n".join(names) + "\n")
+            for arr in ("cv_weights", "cv_norm_mean", "cv_norm_range", "features_norm_mean", "features_norm_range"):
+                buf = io.BytesIO()
+                np.save(buf, golden_linear[f"{cv}.{arr}"])
+                z.writestr(f"model/{arr}.npy", buf.getvalue())
+        calc = CVCalculator.load(str(zpath), str(tmp_path / f"load_{cv}"))
+        out = calc.project_data(torch.from_numpy(X.copy())).numpy()
+        np.testing.assert_allclose(out, golden_proj[cv], atol=1.2e-4)
+        assert match_fraction(out, golden_proj[cv]) > 0.97, cv
+
+
+def test_tica_and_htica_golden(features, golden_linear, tmp_path):
+    X, names = features
+    st = ol.feature_stats(X)
+    m, r = ol.prepare_normalization(st, "mean_std")
+    Xn = ol.normalize(X, m, r)
+    for cv, ref64 in (("tica", ol.tica_cv(Xn, 1, 2, dtype=torch.float64)), ("htica", ol.htica_cv(Xn, 1, 2, 10, 5, dtype=torch.float64))):
+        calc = make_calc(cv, tmp_path)
+        calc.set_training_matrix(X.copy(), names)
+        df = calc.run(2)
+        assert df is not None and df.shape == (164, 2)
+        # ill-conditioned 164 x 54 case (cond(C0) ~ 1e4): 2e-4 vs the float64
+        # restatement, 3e-4 vs the fp32 fixture (its own noise); the 1e-5 bar is checked on the
+        # well-conditioned synthetic case below
+        np.testing.assert_allclose(calc.cv, ref64, atol=2e-4)
+        np.testing.assert_allclose(calc.cv, golden_linear[f"{cv}.cv_weights"], atol=3e-4)
+
+
+def test_tica_htica_pca_synthetic_1e5(tmp_path):
+    """north_star tolerance: CVs within 1e-5 relative of the reference path on well-conditioned data."""
+    from tests.test_mlp_gpu import ar_features
+
+    X = ar_features(60000, 64, 21)
+    st = ol.feature_stats(X)
+    m, r = ol.prepare_normalization(st, "mean_std")
+    Xn = ol.normalize(X, m, r)
+    refs = {"tica": ol.tica_cv(Xn, 10, 3, dtype=torch.float64), "htica": ol.htica_cv(Xn, 10, 3, 4, 5, dtype=torch.float64),
+            "pca": ol.pca_cv(Xn.astype(np.float64), 3)}
+    for cv, ref in refs.items():
+        calc = make_calc(cv, tmp_path, dimension=3, lag_time=10, num_subspaces=4, subspaces_dimension=5)
+        calc.set_training_matrix(X.copy())
+        calc.run(3)
+        err = np.max(np.abs(calc.cv - ref)) / np.max(np.abs(ref))
+        assert err < 1e-5, (cv, err)
+
+
+LENGTHS = [0.785, 0.215]   # 163 pairs -> 128 / 35: two full training batches of 64, no near-singular 3-pair tail batch
+
+
+def _oracle_deeptica(X, m, r, seed, cfg):
+    g = cfg["training"]["general"]
+    data = {"data": torch.from_numpy(X[:-1]), "data_lag": torch.from_numpy(X[1:])}
+    bs = onn.clamp_batch_size(g["batch_size"], 163, LENGTHS[0])
+    res = onn.train(None, data, seed_try=seed, lengths=LENGTHS, batch_size=bs, shuffle=False, random_split=True, max_epochs=g["max_epochs"],
+                    check_val_every_n_epoch=1, save_check_every_n_epoch=1, patience=20, min_delta=1e-5, opt_kwargs={"lr": 1e-3},
+                    model_to_save="last",
+                    build_model=lambda: onn.DeepTICAModel([54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], m, r, 1e-6))
+    onn.finalize_postprocessing(res["model"], torch.from_numpy(X[:-1]))
+    return res
+
+
+def test_deep_tica_calculator_vs_oracle(features, tmp_path):
+    X, names = features
+    training = json.loads(json.dumps(TEST_COMMON["training"]))
+    training["general"]["lengths"] = LENGTHS
+    calc = make_calc("deep_tica", tmp_path, training=training)
+    calc.set_training_matrix(X.copy(), names)
+    df = calc.run(2)
+    assert df is not None and list(df.columns) == ["DeepTIC 1", "DeepTIC 2"]
+    assert calc.batch_size == 64   # 256 >= int(163 * 0.785) = 127 -> closest lower power of two
+    m, r = calc.features_norm_mean, calc.features_norm_range
+    res = _oracle_deeptica(X, m.astype(np.float32), r.astype(np.float32), 43, TEST_COMMON)
+    ref = res["model"]
+    np.testing.assert_allclose(calc.metrics["valid_loss"], res["metrics"]["valid_loss"], rtol=5e-3, atol=5e-4)
+    np.testing.assert_allclose(calc.metrics["train_loss"], res["metrics"]["train_loss"], rtol=5e-3, atol=5e-4)
+    lins = [mod for mod in ref.nn if isinstance(mod, torch.nn.Linear)]
+    for l, ((w, b), lin) in enumerate(zip(calc.cv["linears"], lins)):
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=2e-3)
+    with torch.no_grad():
+        Y = ref(torch.from_numpy(X)).numpy()
+    # the CV itself (sign fixed by the TICA convention), stated tolerance 2e-2 of the [-1, 1] range after 40 epochs
+    assert np.max(np.abs(df.to_numpy() - Y)) < 2e-2
+    # exported TorchScript: reference tree, loads with plain torch.jit, reproduces the projection
+    with zipfile.ZipFile(tmp_path / "deep_tica" / "model.zip") as z:
+        assert sorted(z.namelist()) == ["model/cv_weights.pt", "model/features_labels.txt", "model/metadata.json"]
+        ts = torch.jit.load(io.BytesIO(z.read("model/cv_weights.pt")))
+    assert {n for n, _ in ts.named_parameters()} == {f"nn.nn.{i}.{k}" for i in (0, 3, 6) for k in ("weight", "bias")}
+    assert {n for n, _ in ts.named_buffers()} == {"norm_in.mean", "norm_in.range", "tica.evecs", "tica.mean",
+                                                  "postprocessing.mean", "postprocessing.range"}
+    with torch.no_grad():
+        np.testing.assert_allclose(ts(torch.from_numpy(X)).numpy(), df.to_numpy(), atol=5e-5)
+    from deep_cartograph_amd.cv_calculator import CVCalculator
+
+    loaded = CVCalculator.load(str(tmp_path / "deep_tica" / "model.zip"), str(tmp_path / "reload"))
+    np.testing.assert_allclose(loaded.project_data(torch.from_numpy(X.copy())).numpy(), df.to_numpy(), atol=5e-5)
+    assert (tmp_path / "deep_tica" / "training" / "training_metrics.zip").exists()
+    assert (tmp_path / "deep_tica" / "training" / "eigenvalues.txt").exists()
+
+
+def test_ae_calculator_vs_oracle(features, tmp_path):
+    X, names = features
+    calc = make_calc("ae", tmp_path)
+    calc.set_training_matrix(X.copy(), names)
+    df = calc.run(2)
+    assert df is not None and list(df.columns) == ["AE 1", "AE 2"]
+    m, r = calc.features_norm_mean.astype(np.float32), calc.features_norm_range.astype(np.float32)
+    res = onn.train(None, {"data": torch.from_numpy(X)}, seed_try=43, batch_size=128, shuffle=False, random_split=True, max_epochs=40,
+                    opt_kwargs={"lr": 1e-3}, model_to_save="last",
+                    build_model=lambda: onn.AEModel([54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None],
+                                                    [2, 4, 8, 54], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], m, r))
+    np.testing.assert_allclose(calc.metrics["valid_loss"], res["metrics"]["valid_loss"], rtol=2e-3)
+    ref = onn.finalize_postprocessing(res["model"], torch.from_numpy(X))
+    with torch.no_grad():
+        Y = ref(torch.from_numpy(X)).numpy()
+    assert np.max(np.abs(df.to_numpy() - Y)) < 5e-3
+    with zipfile.ZipFile(tmp_path / "ae" / "model.zip") as z:
+        ts = torch.jit.load(io.BytesIO(z.read("model/cv_weights.pt")))
+    assert {n.split(".")[0] for n, _ in ts.named_parameters()} == {"encoder", "decoder"}
+    with torch.no_grad():
+        np.testing.assert_allclose(ts(torch.from_numpy(X)).numpy(), df.to_numpy(), atol=5e-5)
+
+
+def test_reference_torchscript_zip_loads(features, golden_nn, golden_proj, tmp_path):
+    """A model.zip in the reference's NN format (TorchScript written by our exporter from the
+    reference's parameters / buffers) loads through CVCalculator.load and reproduces the golden CSV."""
+    from deep_cartograph_amd import export
+    from deep_cartograph_amd.cv_calculator import CVCalculator
+
+    X, names = features
+    g = golden_nn
+    lin = [(g[f"deep_tica.param.nn.nn.{i}.weight"], g[f"deep_tica.param.nn.nn.{i}.bias"]) for i in (0, 3, 6)]
+    model = export.DeepTICA(export.Normalization(g["deep_tica.buffer.norm_in.mean"], g["deep_tica.buffer.norm_in.range"]),
+                            export.FeedForward(lin, ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None]),
+                            export.TICA(g["deep_tica.buffer.tica.evecs"], g["deep_tica.buffer.tica.mean"]),
+                            export.Normalization(g["deep_tica.buffer.postprocessing.mean"], g["deep_tica.buffer.postprocessing.range"]))
+    pt = tmp_path / "cv_weights.pt"
+    export.save_torchscript(model, 54, str(pt))
+    zpath = tmp_path / "deep_tica_model.zip"
+    with zipfile.ZipFile(zpath, "w") as z:
+        z.writestr("model/metadata.json", json.dumps({"cv_name": "deep_tica", "cv_dimension": 2}))
+        z.writestr("model/features_labels.txt", "\n".join(names) + "\n")
+        z.write(pt, "model/cv_weights.pt")
+    calc = CVCalculator.load(str(zpath), str(tmp_path / "load"))
+    out = calc.project_data(torch.from_numpy(X.copy())).numpy()
+    np.testing.assert_allclose(out, g["deep_tica.output"], atol=2e-5)
+    assert match_fraction(out, golden_proj["deep_tica"]) > 0.97
+
+
+# ----------------------------------------------------------------------------- clustering
+def test_kmeans_bit_exact_labels(golden_cluster, golden_proj):
+    from deep_cartograph_amd import statistics
+
+    for cv in CVS:
+        P = golden_proj[cv]
+        for k in (3, 6):
+            lab, cen = statistics.cluster_data(P.copy(), {"algorithm": "kmeans", "num_clusters": k, "n_init": 5})
+            np.testing.assert_array_equal(lab, golden_cluster[f"{cv}.kmeans_k{k}_labels"])
+            np.testing.assert_allclose(cen, golden_cluster[f"{cv}.kmeans_k{k}_centroids"], atol=1e-12)
+        lab, cen = statistics.cluster_data(P.copy(), {"algorithm": "kmeans"}, initial_centroids=P[[0, 40, 80, 120]].copy())
+        np.testing.assert_array_equal(lab, golden_cluster[f"{cv}.kmeans_init_labels"])
+        np.testing.assert_allclose(cen, golden_cluster[f"{cv}.kmeans_init_centroids"], atol=1e-12)
+    for tag in ("syn_a", "syn_b", "syn_c"):
+        P = golden_cluster[f"{tag}.points"]
+        lab, cen = statistics.cluster_data(P.copy(), {"algorithm": "kmeans"}, initial_centroids=golden_cluster[f"{tag}.init"].copy())
+        np.testing.assert_array_equal(lab, golden_cluster[f"{tag}.init_labels"])
+        np.testing.assert_allclose(cen, golden_cluster[f"{tag}.init_centroids"], atol=1e-12)
+        k = golden_cluster[f"{tag}.init"].shape[0]
+        lab, cen = statistics.cluster_data(P.copy(), {"algorithm": "kmeans", "num_clusters": k, "n_init": 3})
+        np.testing.assert_array_equal(lab, golden_cluster[f"{tag}.pp_labels"])
+        df = pd.DataFrame(P.copy(), columns=[f"c{i}" for i in range(P.shape[1])])
+        flagged = statistics.find_centroids(df, golden_cluster[f"{tag}.pp_centroids"], list(df.columns))["centroid"].to_numpy()
+        np.testing.assert_array_equal(np.where(flagged)[0], golden_cluster[f"{tag}.pp_centroid_flag_rows"])
+
+
+def test_optimize_clustering_kmeans_and_tool(golden_cluster, golden_proj, tmp_path):
+    from deep_cartograph_amd import statistics, tools
+    from deep_cartograph_amd.schemas import TrajClusterSchema
+
+    for cv in ("pca", "deep_tica"):
+        P = golden_proj[cv]
+        lab, cen = statistics.optimize_clustering(P.copy(), TrajClusterSchema(algorithm="kmeans").model_dump())
+        np.testing.assert_array_equal(lab, golden_cluster[f"{cv}.kmeans_opt_labels"])
+        np.testing.assert_allclose(cen, golden_cluster[f"{cv}.kmeans_opt_centroids"], atol=1e-12)
+    # the reference's own test: defaults (hierarchical) on the golden CSV -> cluster / centroid columns
+    for cv, label in (("pca", "PC"), ("tica", "TIC")):
+        csv = tmp_path / f"{cv}.csv"
+        pd.DataFrame(golden_proj[cv], columns=[f"{label} 1", f"{label} 2"]).to_csv(csv, index=False, float_format="%.4f")
+        out = tools.traj_cluster({}, str(csv), output_folder=str(tmp_path / f"cluster_{cv}"))
+        df = pd.read_csv(out["traj_0"][0])
+        assert list(df.columns) == [f"{label} 1", f"{label} 2", "traj_label", "cluster", "centroid", "frame"]
+        np.testing.assert_array_equal(df["cluster"].to_numpy(), golden_cluster[f"{cv}.golden_cluster"])
+        np.testing.assert_array_equal(df["centroid"].to_numpy(), golden_cluster[f"{cv}.golden_centroid"])
+
+
+def test_train_colvars_tool_end_to_end(features, golden_proj, tmp_path):
+    from deep_cartograph_amd import colvars, deep_carto
+
+    X, names = features
+    path = str(tmp_path / "virtual_dihedrals.dat")
+    colvars.write_colvars(path, X, names)
+    cfg = {"train_colvars": {"cvs": ["pca", "tica", "deep_tica"], "common": json.loads(json.dumps(TEST_COMMON))},
+           "traj_cluster": {"algorithm": "kmeans", "search_interval": [3, 6], "n_init": 3}}
+    cfg["train_colvars"]["common"]["training"]["general"]["max_epochs"] = 5
+    out = deep_carto.deep_cartograph(cfg, [path], sup_colvars_paths=[path], output_folder=str(tmp_path / "run"))
+    assert set(out["train_colvars"]) == {"pca", "tica", "deep_tica"}
+    pca_csv = pd.read_csv(out["train_colvars"]["pca"][0])
+    assert list(pca_csv.columns) == ["PC 1", "PC 2"]
+    assert np.mean(pca_csv.to_numpy() == golden_proj["pca"]) > 0.95   # text colvars carry 8 decimals
+    sup = pd.read_csv(out["traj_projection"]["pca"][0])
+    np.testing.assert_allclose(sup.to_numpy(), pca_csv.to_numpy(), atol=1.01e-4)
+    cl = pd.read_csv(out["traj_cluster"]["pca"]["traj_0"][0])
+    assert {"cluster", "centroid", "frame"} <= set(cl.columns)
+    assert os.path.exists(tmp_path / "run" / "train_colvars" / "configuration.yml")
+    # restart: nothing is recomputed, same paths come back
+    out2 = deep_carto.deep_cartograph(cfg, [path], sup_colvars_paths=[path], restart=True, output_folder=str(tmp_path / "run"))
+    assert out2["train_colvars"] == out["train_colvars"]

@@ -1,0 +1,229 @@
+"""CPU tests of the host-side logic: configuration contract, ingestion, small dense solves,
+export format and the world-size-2 (gloo) reductions of the frame-sharded path."""
+import json
+import os
+import sys
+import zipfile
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import linear as ol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------------------- configuration
+def test_schema_defaults_match_reference_dump():
+    from deep_cartograph_amd.schemas import TrainColvarsSchema, TrajClusterSchema
+
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "schema_defaults.json")))
+    assert json.loads(json.dumps(TrainColvarsSchema().model_dump())) == g["train_colvars"]
+    assert json.loads(json.dumps(TrajClusterSchema().model_dump())) == g["traj_cluster"]
+    # per-CV override sections are accepted as extra fields
+    cfg = TrainColvarsSchema(cvs=["pca"], deep_tica={"lag_time": 7}).model_dump()
+    assert cfg["deep_tica"] == {"lag_time": 7}
+
+
+def test_merge_and_power_of_two(tmp_path):
+    from deep_cartograph_amd.common import closest_power_of_two, merge_configurations, validate_configuration
+    from deep_cartograph_amd.schemas import TrainColvarsSchema
+
+    common = {"a": 1, "t": {"x": 1, "y": {"z": 2}}}
+    out = merge_configurations(common, {"t": {"y": {"z": 3}, "w": 4}, "b": 5})
+    assert out == {"a": 1, "t": {"x": 1, "y": {"z": 3}, "w": 4}, "b": 5}
+    assert common["t"]["y"]["z"] == 2
+    assert [closest_power_of_two(n) for n in (1, 2, 3, 130, 256, 257)] == [1, 2, 2, 128, 256, 256]
+    cfg = validate_configuration({"cvs": ["tica"]}, TrainColvarsSchema, str(tmp_path))
+    assert cfg["common"]["training"]["general"]["batch_size"] == 32
+    assert os.path.exists(tmp_path / "configuration.yml")
+    with pytest.raises(SystemExit):
+        validate_configuration({"cvs": ["nope"]}, TrainColvarsSchema, None)
+
+
+# ----------------------------------------------------------------------------- ingestion
+def test_colvars_loader_text_and_binary(tmp_path, features):
+    from deep_cartograph_amd import colvars
+
+    X, names = features
+    p1 = str(tmp_path / "a.dat")
+    colvars.write_colvars(p1, X, names)
+    p2 = str(tmp_path / "b.npy")
+    colvars.write_binary_matrix(p2, X[:50], names)
+    A, n1, lab = colvars.load_feature_matrix([p1, p2])
+    assert n1 == names and A.shape == (214, 54) and A.dtype == np.float32
+    np.testing.assert_allclose(A[:164], X, atol=1e-7)   # text has 8 decimals
+    np.testing.assert_array_equal(A[164:], X[:50])
+    np.testing.assert_array_equal(lab, [0] * 164 + [1] * 50)
+    # start/stop/stride per file, features_list selection and order, 'time' column dropped
+    sel = [names[5], names[2]]
+    B, n2, _ = colvars.load_feature_matrix(p1, sel, start=3, stop=100, stride=7)
+    assert n2 == sel
+    np.testing.assert_allclose(B, X[3:100:7][:, [5, 2]], atol=1e-7)
+    assert colvars.read_column_names(p1)[0] == "time" and "time" not in colvars.read_column_names(p1, features_only=True)
+    with pytest.raises(ValueError):
+        colvars.load_feature_matrix(p1, ["not_there"])
+    bad = X.copy()
+    bad[3, 3] = np.nan
+    p3 = str(tmp_path / "c.npy")
+    colvars.write_binary_matrix(p3, bad, names)
+    with pytest.raises(ValueError):
+        colvars.load_feature_matrix(p3)
+
+
+# ----------------------------------------------------------------------------- dense solves
+def test_tica_eigh_and_pca_match_oracle(features):
+    from deep_cartograph_amd import linalg
+
+    X, _ = features
+    st = ol.feature_stats(X)
+    m, r = ol.prepare_normalization(st, "mean_std")
+    Xn = ol.normalize(X, m, r).astype(np.float64)
+    xt, xl = Xn[:-1], Xn[1:]
+    mu = xt.mean(0)
+    C0 = (xt - mu).T @ (xt - mu) / len(xt)
+    Ct = (xt - mu).T @ (xl - mu) / len(xt)
+    C0, Ct = 0.5 * (C0 + C0.T), 0.5 * (Ct + Ct.T)
+    ev, V = linalg.tica_eigh(C0, Ct, 1e-6, 2)
+    ev_o, V_o = ol.cholesky_eigh(torch.from_numpy(Ct), torch.from_numpy(C0), 1e-6, 2)
+    np.testing.assert_allclose(ev, ev_o.numpy(), rtol=1e-8)
+    np.testing.assert_allclose(V, V_o.numpy(), atol=1e-8)
+    np.testing.assert_allclose(np.linalg.norm(V, axis=0), 1.0, rtol=1e-12)
+    assert np.all(V[0] >= 0)
+    W = linalg.pca_components(np.cov(Xn.T), 2)
+    np.testing.assert_allclose(W, ol.pca_cv(Xn, 2), atol=1e-8)
+
+
+# ----------------------------------------------------------------------------- export format
+def test_torchscript_tree_matches_reference_names(tmp_path, golden_nn):
+    from deep_cartograph_amd import export
+
+    g = golden_nn
+    lin = [(g[f"deep_tica.param.nn.nn.{i}.weight"], g[f"deep_tica.param.nn.nn.{i}.bias"]) for i in (0, 3, 6)]
+    model = export.DeepTICA(export.Normalization(g["deep_tica.buffer.norm_in.mean"], g["deep_tica.buffer.norm_in.range"]),
+                            export.FeedForward(lin, ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None]),
+                            export.TICA(g["deep_tica.buffer.tica.evecs"], g["deep_tica.buffer.tica.mean"]),
+                            export.Normalization(g["deep_tica.buffer.postprocessing.mean"], g["deep_tica.buffer.postprocessing.range"]))
+    path = str(tmp_path / "cv_weights.pt")
+    export.save_torchscript(model, 54, path)
+    m = torch.jit.load(path)
+    assert m.original_name == "DeepTICA"
+    got_p = {n for n, _ in m.named_parameters()}
+    got_b = {n for n, _ in m.named_buffers()}
+    assert got_p == {k[len("deep_tica.param."):] for k in g.files if k.startswith("deep_tica.param.")}
+    assert got_b == {k[len("deep_tica.buffer."):] for k in g.files if k.startswith("deep_tica.buffer.")}
+    assert [c.original_name for c in m.nn.nn.children()] == ["Linear", "LeakyReLU", "Dropout", "Linear", "LeakyReLU", "Dropout", "Linear"]
+    X = np.load(os.path.join(ROOT, "tests", "golden", "features_164x54.npz"))["X"]
+    with torch.no_grad():
+        out = m(torch.from_numpy(np.ascontiguousarray(X))).numpy()
+    np.testing.assert_allclose(out, g["deep_tica.output"], atol=1e-6)
+    parts = export.read_torchscript(path)
+    assert parts["kind"] == "deep_tica" and parts["acts"] == ["leaky_relu", "leaky_relu", None]
+    np.testing.assert_array_equal(parts["tica"][1], g["deep_tica.buffer.tica.evecs"])
+    # AE tree
+    enc = [(g[f"ae.param.encoder.nn.{i}.weight"], g[f"ae.param.encoder.nn.{i}.bias"]) for i in (0, 3, 6)]
+    dec = [(g[f"ae.param.decoder.nn.{i}.weight"], g[f"ae.param.decoder.nn.{i}.bias"]) for i in (0, 3, 6)]
+    ae = export.AutoEncoderCV(export.Normalization(g["ae.buffer.norm_in.mean"], g["ae.buffer.norm_in.range"]),
+                              export.FeedForward(enc, ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None]),
+                              export.FeedForward(dec, ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None]),
+                              export.Normalization(g["ae.buffer.postprocessing.mean"], g["ae.buffer.postprocessing.range"]))
+    path2 = str(tmp_path / "ae.pt")
+    export.save_torchscript(ae, 54, path2)
+    m2 = torch.jit.load(path2)
+    assert {n for n, _ in m2.named_parameters()} == {k[len("ae.param."):] for k in g.files if k.startswith("ae.param.")}
+    with torch.no_grad():
+        np.testing.assert_allclose(m2(torch.from_numpy(np.ascontiguousarray(X))).numpy(), g["ae.output"], atol=1e-6)
+
+
+def test_zip_layout(tmp_path):
+    from deep_cartograph_amd.common import unzip_files, zip_files
+
+    model = tmp_path / "pca" / "model"
+    model.mkdir(parents=True)
+    (model / "metadata.json").write_text("{}")
+    zip_files(str(tmp_path / "pca" / "model.zip"), str(model))
+    with zipfile.ZipFile(tmp_path / "pca" / "model.zip") as z:
+        assert z.namelist() == ["model/metadata.json"]   # the reference's model.zip layout
+    unzip_files(str(tmp_path / "pca" / "model.zip"), str(tmp_path / "out"))
+    assert (tmp_path / "out" / "model" / "metadata.json").exists()
+
+
+# ----------------------------------------------------------------------------- world size 2 (gloo)
+def _worker(rank, world, port, tmpdir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from deep_cartograph_amd import hip, parallel
+
+    comm = parallel.Comm()
+    rng = np.random.Generator(np.random.PCG64(3))
+    n, F, lag = 101, 6, 4
+    X = rng.standard_normal((n, F)).astype(np.float32)
+    b, e = parallel.shard_bounds(n, world, rank)
+    Xl = torch.from_numpy(X[b:e])
+    # column statistics: per-shard raw sums (NumPy stand-in for the kernel output) -> global
+    X64 = X[b:e].astype(np.float64)
+    raw = torch.from_numpy(np.stack([X64.sum(0), (X64 * X64).sum(0), X64.min(0), X64.max(0)]))
+    raw = parallel.reduce_col_stats(raw, comm)
+    st = hip.finalize_stats(raw, n)
+    ref = ol.feature_stats(X)
+    ok = np.allclose(st["mean"], ref["mean"], atol=1e-6) and np.allclose(st["std"], ref["std"], rtol=1e-5)
+    ok &= np.array_equal(st["min"], ref["min"]) and np.array_equal(st["max"], ref["max"])
+    # halo: the union of the per-shard pair sets is the single-process pair set
+    Xh, npairs = parallel.append_halo(Xl, lag, comm)
+    zt = Xh[:npairs].double().numpy()
+    zl = Xh[lag:lag + npairs].double().numpy()
+    part = np.concatenate([zt.sum(0), zl.sum(0), (zt.T @ zt).ravel(), (zt.T @ zl).ravel()])
+    tot = comm.sum_(torch.from_numpy(part)).numpy()
+    P = n - lag
+    gt, gl = X[:P].astype(np.float64), X[lag:].astype(np.float64)
+    full = np.concatenate([gt.sum(0), gl.sum(0), (gt.T @ gt).ravel(), (gt.T @ gl).ravel()])
+    ok &= np.allclose(tot, full, rtol=1e-12, atol=1e-9)
+    ok &= int(comm.sum_scalar(npairs)) == P
+    _, C0, Ct = hip.covariances_from_raw(tot, P, F)
+    mu = gt.mean(0)
+    ok &= np.allclose(C0, (gt - mu).T @ (gt - mu) / P, atol=1e-12)
+    Ct_ref = (gt - mu).T @ (gl - mu) / P
+    ok &= np.allclose(Ct, 0.5 * (Ct_ref + Ct_ref.T), atol=1e-12)
+    # min/max and nearest-sample reductions
+    mm = parallel.reduce_minmax(torch.from_numpy(np.stack([X64.min(0), X64.max(0)])), comm).numpy()
+    ok &= np.array_equal(mm[0], X.min(0).astype(np.float64)) and np.array_equal(mm[1], X.max(0).astype(np.float64))
+    C = rng.standard_normal((3, F))
+    d = np.linalg.norm(X64[:, None, :] - C[None], axis=2)
+    dist_l = torch.from_numpy(d.min(0))
+    rows_l = torch.from_numpy(d.argmin(0) + b)
+    _, rows = parallel.reduce_nearest(dist_l, rows_l, comm)
+    ok &= np.array_equal(rows.numpy(), np.linalg.norm(X.astype(np.float64)[:, None, :] - C[None], axis=2).argmin(0))
+    with open(os.path.join(tmpdir, f"ok_{rank}"), "w") as f:
+        f.write("1" if ok else "0")
+    dist.destroy_process_group()
+
+
+def test_sharded_reductions_world2(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert (tmp_path / f"ok_{r}").read_text() == "1"
+
+
+def test_calculators_refuse_cpu():
+    from deep_cartograph_amd._lib import DcvError
+    from deep_cartograph_amd.cv_calculator import cv_calculators_map
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    assert set(cv_calculators_map) == {"pca", "tica", "htica", "ae", "deep_tica"}
+    calc = cv_calculators_map["pca"]({"dimension": 2, "features_normalization": "mean_std"}, "/tmp/x")
+    with pytest.raises(DcvError):
+        calc.set_training_matrix(np.zeros((10, 4), dtype=np.float32))

@@ -197,6 +197,11 @@ def main():
             flops[(layer, kind)] = (fl, ms / cnt)
         (dl, dk), (dfl, dms) = max(flops.items(), key=lambda kv: kv[1][1])
         achieved = dfl / (dms * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (same launch shape)
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath) and lb == 65536 and F == 512 and dims[1] == 256:
+            traffic = json.load(open(tpath))["kernels"].get(f"layer{dl}.{dk}", {}).get("hbm_bytes_per_launch")
         sw = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
         losses = log[:, 0]
         out = {
@@ -223,7 +228,7 @@ def main():
             "loss_last_train": float(losses[-1]) if len(losses) else None,
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "kernel": f"layer{dl}.{dk} (gemm_kernel, FP32 MFMA 32x32x2)", "flop_per_launch": dfl, "avg_ms": dms,
                 "all_kernels_ms": {f"layer{l}.{k}": v[1] for (l, k), v in sorted(flops.items())},
             },

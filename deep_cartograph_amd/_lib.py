@@ -61,6 +61,7 @@ SIGNATURES = {
     "dcv_mlp_set_params": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_get_params": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_set_lr": (C.c_int, [_P, C.c_double]),
+    "dcv_mlp_set_row_sharing": (C.c_int, [_P, _I32]),
     "dcv_mlp_set_feature_range": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_forward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_stats": (_P, [_P]),

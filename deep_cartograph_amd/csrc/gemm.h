@@ -73,6 +73,7 @@ struct GemmDims {
     int64_t M, N, K;
     int64_t k_chunk;  // TN: contraction rows per blockIdx.z (K for the others)
     int tiles_m, tiles_n;
+    int xcd_remap;    // XCD-aware block -> tile map enabled (launch-time decision)
 };
 
 template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_>

@@ -130,14 +130,38 @@ inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reint
 template <int MODE, class Cfg, int NB, bool VEC, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
-    const int tile = blockIdx.x;
-    const int tile_m = tile / d.tiles_n;
-    const int tile_n = tile - tile_m * d.tiles_n;
+    // XCD-aware block -> (tile, split) map.  Blocks b and b + 8 are observed to share an XCD (and its
+    // L2); the workgroups that read the same rows -- the column tiles of one row tile (NT / NN), the
+    // output tiles of one contraction chunk (TN) -- are therefore given ids that are congruent mod 8.
+    // Placement is a speed heuristic only: any dispatch order computes the same result.
+    int tile_m, tile_n;
     int64_t k_begin = 0, k_end = d.K;
     if constexpr (MODE == kTN) {
-        k_begin = (int64_t)blockIdx.z * d.k_chunk;
+        const int T = d.tiles_m * d.tiles_n;
+        const int splits = gridDim.z;
+        int tile = blockIdx.x, split = blockIdx.z;
+        if (d.xcd_remap) {
+            const int lin = blockIdx.z * T + blockIdx.x;
+            const int xcd = lin & 7, q = lin >> 3;
+            tile = q % T;
+            split = (q / T) * 8 + xcd;
+        }
+        (void)splits;
+        tile_m = tile / d.tiles_n;
+        tile_n = tile - tile_m * d.tiles_n;
+        k_begin = (int64_t)split * d.k_chunk;
         k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
-        if constexpr (std::is_same<Epi, EpiSlab>::value) epi.z = blockIdx.z;
+        if constexpr (std::is_same<Epi, EpiSlab>::value) epi.z = split;
+    } else {
+        int tile = blockIdx.x;
+        if (d.xcd_remap) {
+            const int xcd = tile & 7, q = tile >> 3;
+            tile_n = q % d.tiles_n;
+            tile_m = (q / d.tiles_n) * 8 + xcd;
+        } else {
+            tile_m = tile / d.tiles_n;
+            tile_n = tile - tile_m * d.tiles_n;
+        }
     }
     gemm_block<MODE, Cfg, NB, VEC, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
 }
@@ -146,6 +170,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
 #define DCV_BIGCFG TileCfg<2, 2, 2, 2, 32>
 #endif
 using CfgBig = DCV_BIGCFG;  // 128 x 128
+using CfgHalfM = TileCfg<2, 2, 1, 2, 32>;    // 64 x 128: twice the workgroups when the row count is small
 using CfgNarrowN = TileCfg<4, 1, 1, 1, 32>;  // 128 x 32
 using CfgNarrowM = TileCfg<1, 4, 1, 1, 32>;  // 32 x 128
 using CfgCov = TileCfg<2, 2, 2, 2, 16>;      // 128 x 128, two B operands, 48 KiB LDS
@@ -179,6 +204,13 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
     d.tiles_m = (int)cdiv(M, Cfg::TM);
     d.tiles_n = (int)cdiv(N, Cfg::TN);
     if (tiles_m_out) *tiles_m_out = d.tiles_m;
+    {
+        static int env = -1;
+        if (env < 0) { const char* e = getenv("DCV_XCD_REMAP"); env = e ? atoi(e) : 1; }
+        const int64_t nsplit = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
+        // bijective only when the remapped index is a multiple of 8
+        d.xcd_remap = env && ((MODE == kTN) ? (nsplit % 8 == 0) : (d.tiles_m % 8 == 0 && d.tiles_n > 1));
+    }
     const int64_t splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
     const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
     DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
@@ -190,12 +222,23 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
     return launch_gemm_vec<MODE, Cfg, NB, false, Epi>(A, B, lag2, d, splits, epi, s);
 }
 
-// Picks the tile shape from the output extents.
+// Picks the tile shape from the output extents.  Row-parallel products (NT / NN) fall back to
+// shorter tiles when 128-row tiles would leave CUs without two resident workgroups (small per-GPU
+// batches of a multi-GPU run); TN products get their parallelism from the split count instead.
 template <int MODE, class Epi>
 static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
                        const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
     if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowN, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
     if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    if constexpr (MODE != kTN) {
+        const int64_t want = 2 * (int64_t)num_cus();
+        const int64_t tn = cdiv(N, 128);
+        if (cdiv(M, 128) * tn < want) {
+            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return launch_gemm_cfg<MODE, CfgHalfM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            if (cdiv(M, 64) * tn < want / 2) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            return launch_gemm_cfg<MODE, CfgHalfM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+        }
+    }
     return launch_gemm_cfg<MODE, CfgBig, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
 }
 

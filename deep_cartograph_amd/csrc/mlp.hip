@@ -61,6 +61,7 @@ struct dcv_mlp {
     double lr;
     // bookkeeping of the last forward (backward must match)
     int32_t last_batch;
+    int no_row_sharing;        // diagnostic: evaluate contiguous Deep-TICA batches as two separate halves
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
     int prof_level, prof_cap, prof_step;
     std::vector<hipEvent_t> prof_ev;  // [class][step][2], class = 3*layer + {0 fwd, 1 wgrad, 2 dgrad}
@@ -72,15 +73,31 @@ constexpr int kColsumRows = 128;
 constexpr int kStatBlockRows = 128;
 
 // ------------------------------------------------------------------ small kernels
-// partial column sums of dZ (rows x n): part[block][n]
+// partial column sums of dZ (rows x n): part[block][n], one block per kColsumRows rows.  Threads are
+// laid out (row group, column): wide matrices give every thread one column, narrow ones (the d
+// outputs of the last layer) put many row groups on one column and combine them through LDS.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Z, int64_t rows, int n, int64_t ld,
                                                      float* __restrict__ part) {
+    __shared__ float red[256];
     const int64_t r0 = (int64_t)blockIdx.x * kColsumRows;
     const int64_t r1 = r0 + kColsumRows < rows ? r0 + kColsumRows : rows;
-    for (int c = threadIdx.x; c < n; c += 256) {
+    const int t = threadIdx.x;
+    const int cols = n < 256 ? n : 256;   // columns handled per pass
+    const int groups = 256 / cols;        // row groups per column
+    const int c_in = t % cols, g = t / cols;
+    for (int c0 = 0; c0 < n; c0 += cols) {
+        const int c = c0 + c_in;
         float s = 0.f;
-        for (int64_t r = r0; r < r1; ++r) s += Z[r * ld + c];
-        part[(int64_t)blockIdx.x * n + c] = s;
+        if (g < groups && c < n)
+            for (int64_t r = r0 + g; r < r1; r += groups) s += Z[r * ld + c];
+        red[t] = s;
+        __syncthreads();
+        if (g == 0 && c < n) {
+            float tot = 0.f;
+            for (int q = 0; q < groups; ++q) tot += red[q * cols + c_in];
+            part[(int64_t)blockIdx.x * n + c] = tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -152,10 +169,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 }
 
 // ------------------------------------------------------------------ Deep-TICA batch statistics
-// F: rows [0,B) = f_t, rows [B,2B) = f_lag, d columns.  Each block stages kStatBlockRows pairs in
+// F: f_t of sample r in row r, f_lag in row r + lag_off, d columns (lag_off = B when the two halves
+// of the batch are separate rows, = lag when a contiguous batch shares its rows: see dcv_mlp_forward).
+// Each block stages kStatBlockRows pairs in
 // LDS (float64) and every thread owns whole outputs of [sum f_t | sum f_lag | sum f_t f_t^T |
 // sum f_t f_lag^T]; part[block][2d + 2d^2] float64, combined in block order afterwards.
-__global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict__ F, int64_t ld, int B, int d,
+__global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict__ F, int64_t ld, int B, int d, int lag_off,
                                                          double* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double* s_t = reinterpret_cast<double*>(smem);   // [rows][d]
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict
     for (int i = t; i < nr * d; i += 256) {
         const int r = i / d, c = i - r * d;
         s_t[i] = (double)F[(r0 + r) * ld + c];
-        s_l[i] = (double)F[(r0 + r + B) * ld + c];
+        s_l[i] = (double)F[(r0 + r + lag_off) * ld + c];   // lag_off = B (two halves) or lag (shared rows)
     }
     __syncthreads();
     double* my = part + (int64_t)blockIdx.x * W;
@@ -364,8 +383,12 @@ static TicaGradFn tica_grad_fn(int d) {
     }
 }
 
-// dZ_last rows: t rows get Gu u + Gv v + c, lag rows get Gv u  (then * act'(F) of the last layer)
-__global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ F, int64_t ldf, int B, int d,
+// Gradient of the loss w.r.t. the network outputs.  Sample i (0 <= i < B) has f_t in row i and f_lag in
+// row i + lag_off:  dL/df_t[i] = Gu u_i + Gv v_i + c,  dL/df_lag[i] = Gv u_i  (u = f_t - mu, v = f_lag - mu).
+// Row j of dZ collects whatever lands on it: its own t-gradient (j < B) plus the lag-gradient of sample
+// j - lag_off (j >= lag_off).  With lag_off = B the halves are disjoint; with lag_off = lag (contiguous
+// batch, shared rows) an interior row receives both.  Multiplied by act'(F) of the last layer.
+__global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ F, int64_t ldf, int B, int d, int lag_off,
                                                       const float* __restrict__ gradp, int act, float* __restrict__ dZ,
                                                       int64_t ldz) {
     __shared__ float s_g[kMaxTicaDim * (2 * kMaxTicaDim + 2)];
@@ -376,24 +399,34 @@ __global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ 
     const float* Gu = s_g + d;
     const float* Gv = Gu + d * d;
     const float* cv = Gv + d * d;
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= B) return;
-    float u[kMaxTicaDim], v[kMaxTicaDim];
-    const float* ft = F + r * ldf;
-    const float* fl = F + (r + B) * ldf;
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t rows = (int64_t)B + lag_off;
+    if (j >= rows) return;
+    const bool has_t = j < B;            // row j is the f_t row of sample j
+    const bool has_l = j >= lag_off;     // row j is the f_lag row of sample j - lag_off
+    float u[kMaxTicaDim], v[kMaxTicaDim], w[kMaxTicaDim], fj[kMaxTicaDim];
+    const float* frow = F + j * ldf;
     for (int i = 0; i < d; ++i) {
-        u[i] = ft[i] - mu[i];
-        v[i] = fl[i] - mu[i];
+        fj[i] = frow[i];
+        u[i] = fj[i] - mu[i];                                               // u_j
+        v[i] = has_t ? F[(j + lag_off) * ldf + i] - mu[i] : 0.f;           // v_j
+        w[i] = has_l ? F[(j - lag_off) * ldf + i] - mu[i] : 0.f;           // u_{j - lag_off}
     }
     for (int i = 0; i < d; ++i) {
-        float gt = cv[i], gl = 0.f;
-        for (int j = 0; j < d; ++j) {
-            gt = fmaf(Gu[i * d + j], u[j], gt);
-            gt = fmaf(Gv[i * d + j], v[j], gt);
-            gl = fmaf(Gv[i * d + j], u[j], gl);
+        float g = 0.f;
+        if (has_t) {
+            g = cv[i];
+            for (int q = 0; q < d; ++q) {
+                g = fmaf(Gu[i * d + q], u[q], g);
+                g = fmaf(Gv[i * d + q], v[q], g);
+            }
         }
-        dZ[r * ldz + i] = gt * act_grad_from_out(act, ft[i]);
-        dZ[(r + B) * ldz + i] = gl * act_grad_from_out(act, fl[i]);
+        if (has_l) {
+            float gl = 0.f;
+            for (int q = 0; q < d; ++q) gl = fmaf(Gv[i * d + q], w[q], gl);
+            g += gl;
+        }
+        dZ[j * ldz + i] = g * act_grad_from_out(act, fj[i]);
     }
 }
 
@@ -464,12 +497,23 @@ static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStre
     (void)hipEventRecord(m->prof_ev[(cls * m->prof_cap + m->prof_step) * 2 + which], s);
 }
 
+// Deep-TICA batches.  Gathered batch (idx given): rows [0,B) are the x_t rows, rows [B,2B) the x_lag rows.
+// Contiguous batch (row0 .. row0+B-1, the sequential-split / unshuffled case): x_lag of sample i IS x_t of
+// sample i + lag, so the network is evaluated once on the B + lag rows row0 .. row0+B+lag-1 and both
+// halves read the shared outputs -- the same numbers as two separate passes (every row goes through the
+// same weights), about half the matrix work.  The gradient of a shared row is the sum of its two roles.
+static bool shared_rows(const dcv_mlp* m, const int64_t* idx, int batch) {
+    return m->desc.model == DCV_MODEL_DEEPTICA && idx == nullptr && m->desc.lag >= 1 && m->desc.lag <= batch && !m->no_row_sharing;
+}
 static RowMap batch_rows(const dcv_mlp* m, const int64_t* idx, int64_t row0, int batch) {
-    if (m->desc.model == DCV_MODEL_DEEPTICA) return RowMap{idx, row0, batch, m->desc.lag};
+    if (m->desc.model == DCV_MODEL_DEEPTICA && !shared_rows(m, idx, batch)) return RowMap{idx, row0, batch, m->desc.lag};
     return RowMap{idx, row0, 0, 0};
 }
-
-static int64_t rows_of(const dcv_mlp* m, int batch) { return m->desc.model == DCV_MODEL_DEEPTICA ? 2 * (int64_t)batch : batch; }
+static int64_t rows_of(const dcv_mlp* m, const int64_t* idx, int batch) {
+    if (m->desc.model != DCV_MODEL_DEEPTICA) return batch;
+    return shared_rows(m, idx, batch) ? (int64_t)batch + m->desc.lag : 2 * (int64_t)batch;
+}
+static int lag_offset(const dcv_mlp* m, const int64_t* idx, int batch) { return shared_rows(m, idx, batch) ? m->desc.lag : batch; }
 
 // wgrad split plan: enough workgroups to fill the chip twice, chunks a multiple of 32 rows
 static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t* splits) {
@@ -530,7 +574,8 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->desc = *desc;
     m->L = L;
     m->d_out = desc->dims[L];
-    m->rows_cap = rows_of(m, desc->max_batch);
+    m->no_row_sharing = 0;
+    m->rows_cap = m->desc.model == DCV_MODEL_DEEPTICA ? 2 * (int64_t)desc->max_batch : desc->max_batch;
     m->lr = desc->lr;
     m->adam_t = 0;
     m->last_batch = 0;
@@ -556,7 +601,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         if (p.max_splits < 1) p.max_splits = 1;
         rc = dmalloc(&p.H, (size_t)m->rows_cap * p.ldh);
         if (rc == DCV_OK) rc = dmalloc(&p.slab, (size_t)p.max_splits * p.in * p.out);
-        if (rc == DCV_OK) rc = dmalloc(&p.bpart, (size_t)cdiv(m->rows_cap, kColsumRows) * p.out);
+        if (rc == DCV_OK) rc = dmalloc(&p.bpart, (size_t)cdiv(m->rows_cap, 32) * p.out);  // row tiles of the dgrad epilogue can be as short as 32
     }
     m->n_params = off;
     m->ld_dz = align_up((size_t)maxdim, 4);
@@ -642,6 +687,12 @@ extern "C" int dcv_mlp_get_params(dcv_mlp* m, float* params_h, void* stream) {
     return DCV_OK;
 }
 
+extern "C" int dcv_mlp_set_row_sharing(dcv_mlp* m, int32_t enable) {
+    DCV_REQUIRE(m, "dcv_mlp_set_row_sharing: null");
+    m->no_row_sharing = enable ? 0 : 1;
+    return DCV_OK;
+}
+
 extern "C" int dcv_mlp_set_lr(dcv_mlp* m, double lr) {
     DCV_REQUIRE(m, "dcv_mlp_set_lr: null");
     m->lr = lr;
@@ -710,14 +761,14 @@ extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const 
     DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_forward: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
     hipStream_t s = as_stream(stream);
     const RowMap rm = batch_rows(m, idx_d, row0, batch);
-    const int64_t R = rows_of(m, batch);
+    const int64_t R = rows_of(m, idx_d, batch);
     int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s);
     if (rc) return rc;
     const LayerPlan& last = m->layers[m->L - 1];
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
         const int nb = (int)cdiv(batch, kStatBlockRows);
         hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, last.H,
-                           last.ldh, batch, m->d_out, m->spart);
+                           last.ldh, batch, m->d_out, lag_offset(m, idx_d, batch), m->spart);
         DCV_CHECK_LAUNCH();
         hipLaunchKernelGGL(sum_partials_kernel, dim3(m->stats_len), dim3(64), 0, s, m->spart, nb, m->stats_len, m->stats);
         DCV_CHECK_LAUNCH();
@@ -743,7 +794,7 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp_backward: call dcv_mlp_reset_log first");
     hipStream_t s = as_stream(stream);
     const RowMap rm = batch_rows(m, idx_d, row0, batch);
-    const int64_t R = rows_of(m, batch);
+    const int64_t R = rows_of(m, idx_d, batch);
     const int L = m->L;
     const LayerPlan& last = m->layers[L - 1];
     float* dz_cur = m->dZ[0];
@@ -753,8 +804,8 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
                            train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
         DCV_CHECK_LAUNCH();
         if (!train) return DCV_OK;
-        hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(batch, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
-                           m->gradp, last.act, dz_cur, m->ld_dz);
+        hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
+                           lag_offset(m, idx_d, batch), m->gradp, last.act, dz_cur, m->ld_dz);
         DCV_CHECK_LAUNCH();
     } else {
         const int F = m->desc.dims[0];

@@ -303,6 +303,10 @@ class Mlp:
     def set_lr(self, lr: float):
         check(self.lib.dcv_mlp_set_lr(self.h, float(lr)), "dcv_mlp_set_lr")
 
+    def set_row_sharing(self, enable: bool):
+        """Deep-TICA contiguous batches: share the rows of the two halves (default) or not."""
+        check(self.lib.dcv_mlp_set_row_sharing(self.h, 1 if enable else 0), "dcv_mlp_set_row_sharing")
+
     def set_feature_range(self, rng):
         r = np.ascontiguousarray(np.asarray(rng, dtype=np.float32))
         check(self.lib.dcv_mlp_set_feature_range(self.h, r.ctypes.data, _stream()), "dcv_mlp_set_feature_range")

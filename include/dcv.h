@@ -143,12 +143,19 @@ float* dcv_mlp_grads(dcv_mlp* m);
 int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* stream);
 int dcv_mlp_get_params(dcv_mlp* m, float* params_h, void* stream);
 int dcv_mlp_set_lr(dcv_mlp* m, double lr);
+/* Deep-TICA, contiguous batches (idx_d == NULL, 1 <= lag <= batch): x_lag of sample i is x_t of sample
+ * i + lag, so by default the network is evaluated once on the batch + lag rows both halves share
+ * (identical outputs, about half the matrix work; the gradient of a shared row is the sum of its two
+ * roles).  enable = 0 evaluates the two halves separately (2 * batch rows), as gathered batches always
+ * are -- used by the parity tests to check that both forms agree. */
+int dcv_mlp_set_row_sharing(dcv_mlp* m, int32_t enable);
 /* AE only: per-feature range of norm_in (device copy is made); needed by the loss. */
 int dcv_mlp_set_feature_range(dcv_mlp* m, const float* range_h, void* stream);
 
 /* One optimisation / evaluation step, split in phases so that a data-parallel caller can
  * all-reduce between them.  Samples of the batch: idx_d != NULL => sample j uses row
- * idx_d[j] (int64, device) else row row0 + j; Deep-TICA also reads row + lag.
+ * idx_d[j] (int64, device) else row row0 + j; Deep-TICA also reads row + lag (rows row0 .. row0 +
+ * batch + lag - 1 must exist).
  * `global_batch` is the number of samples over ALL ranks (= batch on one GPU).
  *
  *   dcv_mlp_forward   forward pass; Deep-TICA: leaves the batch statistics

@@ -102,6 +102,43 @@ def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather):
     eng.close()
 
 
+def test_deeptica_row_sharing_equivalence():
+    """Contiguous batches evaluate the network once on the batch + lag rows both halves share; the
+    result must equal the two-halves evaluation (same rows through the same weights)."""
+    from deep_cartograph_amd import hip
+
+    n, F, lag, batch = 5000, 96, 7, 1500
+    dims, acts = [F, 48, 24, 3], ["leaky_relu", "tanh", None]
+    Xn, _, _ = normalized(ar_features(n, F, 9))
+    torch.manual_seed(5)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    Xd = torch.from_numpy(Xn).cuda()
+    out = {}
+    for share in (True, False):
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+        push_params(eng, linears_of(ref.nn))
+        eng.set_row_sharing(share)
+        eng.reset_log(2)
+        eng.forward(Xd, row0=11, batch=batch)
+        stats = eng.stats_view().cpu().numpy().copy()
+        eng.backward(Xd, row0=11, batch=batch)
+        out[share] = (stats, eng.read_log()[0].copy(), eng.grads_view().cpu().numpy().copy())
+        eng.close()
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-12)   # identical outputs -> identical float64 sums
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=1e-10)
+    g1, g0 = out[True][2], out[False][2]
+    assert np.max(np.abs(g1 - g0)) < 2e-6 * np.max(np.abs(g0))           # same gradient, different fp32 summation order
+    # and a gathered batch with the same samples agrees too
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+    push_params(eng, linears_of(ref.nn))
+    eng.reset_log(2)
+    idx = torch.arange(11, 11 + batch).cuda()
+    eng.forward(Xd, idx=idx)
+    eng.backward(Xd, idx=idx)
+    np.testing.assert_allclose(eng.read_log()[0], out[True][1], rtol=1e-10)
+    eng.close()
+
+
 def test_deeptica_training_matches_oracle():
     from deep_cartograph_amd import hip
 

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""Secondary measurements on one MI355X for the other BASELINE.json configurations (they are
+parity-test cases, not the headline bench line): C3 TICA + hTICA 5M x 256, C2 AE 1M x 128, and the
+projection / k-means passes of C5 at reduced frame counts.  Prints one JSON object per config."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from deep_cartograph_amd import hip, statistics  # noqa: E402
+from deep_cartograph_amd.cv_calculator import cv_calculators_map  # noqa: E402
+from deep_cartograph_amd.synth import synth_features  # noqa: E402
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def timed(fn, reps=3):
+    fn()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    sync()
+    return (time.perf_counter() - t0) / reps
+
+
+def c3(n=5_000_000, F=256, lag=10):
+    X = synth_features(n, F, k_slow=4, device="cuda")
+    out = {"config": f"C3 TICA + hTICA, {n}x{F}, lag {lag}"}
+    t_stats = timed(lambda: hip.col_stats_raw(X))
+    out["col_stats_GBps"] = 4.0 * n * F / t_stats / 1e9
+    st = hip.finalize_stats(hip.col_stats_raw(X), n)
+    m = torch.from_numpy(st["mean"]).cuda()
+    r = torch.from_numpy(st["std"]).cuda()
+    t_norm = timed(lambda: hip.normalize(X, m, r, out=X), reps=1)
+    out["normalize_GBps"] = 8.0 * n * F / t_norm / 1e9
+    P = n - lag
+    t_cov = timed(lambda: hip.lagged_cov_raw(X, P, lag))
+    out["lagged_cov_ms"] = t_cov * 1e3
+    out["lagged_cov_TFLOPs"] = 4.0 * P * F * F / t_cov / 1e12
+    out["lagged_cov_frac_of_157.3"] = out["lagged_cov_TFLOPs"] / 157.3
+    t_pca = timed(lambda: hip.lagged_cov_raw(X, n, 0))
+    out["pca_cov_TFLOPs"] = 2.0 * n * F * F / t_pca / 1e12
+    W = torch.randn(F, 2, device="cuda") / 16
+    t_proj = timed(lambda: hip.project_linear(X, W, want_minmax=True))
+    out["project_linear_GBps"] = (4.0 * n * F + 8.0 * n) / t_proj / 1e9
+    # end-to-end calculators (fit + normalise CV + project training frames; no file output)
+    for cv in ("tica", "htica"):
+        cfg = {"dimension": 2, "lag_time": lag, "features_normalization": None, "num_subspaces": 10, "subspaces_dimension": 5}
+        calc = cv_calculators_map[cv](cfg, "/tmp/dcv_bench_out")
+        sync()
+        t0 = time.perf_counter()
+        calc.set_training_matrix(X)
+        calc.create_output_folders()
+        calc.compute_cv()
+        calc.set_labels()
+        calc.normalize_cv()
+        proj = calc.project_data(calc.training_data, normalize_data=False)
+        sync()
+        dt = time.perf_counter() - t0
+        out[f"{cv}_fit_project_s"] = dt
+        out[f"{cv}_frames_per_s"] = n / dt
+    del X
+    torch.cuda.empty_cache()
+    return out
+
+
+def c2(n=1_000_000, F=128, epochs=3):
+    X = synth_features(n, F, k_slow=2, device="cuda")
+    cfg = {"dimension": 2, "features_normalization": "mean_std",
+           "architecture": {"encoder": {"layers": [64, 32], "activation": ["leaky_relu", "leaky_relu"]},
+                            "decoder": {"layers": [32, 64], "activation": ["leaky_relu", "leaky_relu"]}},
+           "training": {"general": {"num_tries": 1, "seed": 42, "lengths": [0.8, 0.2], "batch_size": 4096, "max_epochs": epochs,
+                                    "shuffle": False, "random_split": False, "check_val_every_n_epoch": 1, "save_check_every_n_epoch": 1},
+                        "early_stopping": {"patience": 100, "min_delta": 0.0}, "optimizer": {"name": "Adam", "kwargs": {"lr": 1e-3}},
+                        "lr_scheduler": None, "model_to_save": "last", "save_loss": False}}
+    calc = cv_calculators_map["ae"](cfg, "/tmp/dcv_bench_out")
+    calc.set_training_matrix(X)
+    calc.create_output_folders()
+    sync()
+    t0 = time.perf_counter()
+    ok = calc.train()
+    sync()
+    dt = time.perf_counter() - t0
+    return {"config": f"C2 AE {F}-64-32-2-32-64-{F}, {n}x{F}, batch 4096, {epochs} epochs (train 0.8 + validation 0.2 per epoch)",
+            "ok": bool(ok), "fit_s": dt, "train_frames_per_s": 0.8 * n * epochs / dt, "losses": calc.metrics["valid_loss"]}
+
+
+def c5_parts(n=20_000_000, d=4, k=6):
+    rng = np.random.Generator(np.random.PCG64(7))
+    mu = rng.uniform(-0.8, 0.8, size=(k, d))
+    P = torch.from_numpy(mu)[torch.randint(0, k, (n,))].cuda() + 0.08 * torch.randn(n, d, dtype=torch.float64, device="cuda")
+    P = (P.clamp(-1, 1) * 1e4).round() / 1e4
+    C = P[torch.randperm(n, device="cuda")[:k]].clone()
+    labels = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    t = timed(lambda: hip.kmeans_step(P, C, labels))
+    out = {"config": f"C5 k-means pass, {n}x{d} float64, k={k}", "kmeans_step_ms": t * 1e3, "kmeans_GBps": (8.0 * d + 8.0) * n / t / 1e9}
+    t2 = timed(lambda: hip.nearest_rows(P, C))
+    out["nearest_rows_ms"] = t2 * 1e3
+    Ph = P.cpu().numpy()
+    t0 = time.perf_counter()
+    lab, cen = statistics.kmeans_clustering(Ph, k, 1, initial_centroids=C.cpu().numpy())
+    out["kmeans_full_fit_s"] = time.perf_counter() - t0
+    out["cluster_sizes"] = np.bincount(lab, minlength=k).tolist()
+    return out
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3", "c2", "c5"]
+    for w in which:
+        print(json.dumps({"c3": c3, "c2": c2, "c5": c5_parts}[w]()), flush=True)

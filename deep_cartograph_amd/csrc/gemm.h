@@ -52,10 +52,15 @@ struct RowMap {
     int64_t row0;
     int32_t half;
     int32_t lag;
-    __device__ __forceinline__ int64_t operator()(int64_t r) const {
+    // GATHER is a compile-time property of the kernel instantiation: without it no index load (and
+    // no wait on the vector-memory counter) is generated at all
+    template <bool GATHER>
+    __device__ __forceinline__ int64_t get(int64_t r) const {
         const bool second = half > 0 && r >= half;
         const int64_t j = second ? r - half : r;
-        const int64_t base = idx ? idx[j] : row0 + j;
+        int64_t base;
+        if constexpr (GATHER) base = idx ? idx[j] : row0 + j;
+        else base = row0 + j;
         return second ? base + lag : base;
     }
 };
@@ -102,14 +107,33 @@ __device__ __forceinline__ int mmajor_off(int row, int chunk) {
 //     64 lanes of a wave write 1 KiB contiguously, no VGPR round trip, no ds_write;
 //   * through registers (ragged edges, scalar loads, covariance shift): loads carry no arithmetic
 //     so they all stay in flight across the MFMA phase; the shift is applied at LDS-store time.
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// Issued through inline asm on purpose: hipcc treats the builtin form as an LDS write it must
+// order against later ds_reads and waits vmcnt(0) right after issuing it, which serialises the
+// DMA with the MFMA phase.  The asm form is outside the compiler's vmcnt bookkeeping; completion
+// is awaited explicitly (stage_fence: s_waitcnt vmcnt(0) + barrier) before the image is read.
+// M0 carries the wave-uniform LDS byte address; it is compiler-reserved, so it is saved / restored
+// inside the same statement (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_wave_addr) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_addr)
+        : "memory");
+}
+// LDS byte address of a pointer into the dynamic shared array, made provably wave-uniform
+__device__ __forceinline__ unsigned lds_addr_uniform(const float* p) {
+    const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)p;
+    return __builtin_amdgcn_readfirstlane(a);
 }
 
 // MMAJOR tile [T][KB]: unit u = t + 256*i -> row = u / CPR, slot = u % CPR.  A thread's rows are
 // the same in every stage, so their base pointers are resolved once.
-template <int T, int KB, bool VEC>
+template <int T, int KB, bool VEC, bool GATHER>
 struct MMajorStage {
     static constexpr int CPR = KB / 4;
     static constexpr int RPBR = 64 / KB;
@@ -130,13 +154,13 @@ struct MMajorStage {
             const int u = t + 256 * i;
             const int64_t m = m0 + u / CPR;
             const bool ok = (UNITS % 256 == 0 || u < UNITS) && m < m_end;
-            src[i] = ok ? op.p + op.rows(m) * op.ld + kofs : nullptr;
+            src[i] = ok ? op.p + op.rows.template get<GATHER>(m) * op.ld + kofs : nullptr;
         }
     }
     __device__ __forceinline__ bool dense(int64_t k0, int64_t k_end) const { return VEC && all_rows && k0 + KB <= k_end; }
     __device__ __forceinline__ void glds(int64_t k0, float* lds, int t) const {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) glds16(src[i] + k0, lds + ((t & ~63) + 256 * i) * 4);
+        for (int i = 0; i < PER; ++i) glds16(src[i] + k0, lds_addr_uniform(lds + ((t & ~63) + 256 * i) * 4));
     }
     __device__ __forceinline__ void load(int64_t k0, int64_t k_end) {
         if (dense(k0, k_end)) {  // uniform: unconditional 16-byte loads
@@ -172,7 +196,7 @@ struct MMajorStage {
 // KMAJOR tile [KB][T]: unit u -> krow = u / (T/4), c4 = u % (T/4).  A thread's columns are the
 // same in every stage (and in every unit, since 256 % (T/4) == 0).  The matrix rows of a stage
 // are resolved one stage ahead (resolve()), so a gathering row map costs no exposed latency.
-template <int T, int KB, bool VEC>
+template <int T, int KB, bool VEC, bool GATHER>
 struct KMajorStage {
     static constexpr int C4 = T / 4;
     static constexpr int UNITS = KB * C4;
@@ -211,14 +235,14 @@ struct KMajorStage {
             const int u = t + 256 * i;
             const int64_t k = k0 + u / C4;
             const bool ok = (UNITS % 256 == 0 || u < UNITS) && k < k_end && ncol > 0;
-            rowv[i] = ok ? op.rows(k) + row_off : -1;
+            rowv[i] = ok ? op.rows.template get<GATHER>(k) + row_off : -1;
         }
     }
     __device__ __forceinline__ bool dense(int64_t k0, int64_t k_end) const { return all_cols && k0 + KB <= k_end; }
     // both loaders fetch the stage resolved by the previous resolve() call
     __device__ __forceinline__ void glds(float* lds, int t) const {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) glds16(base + rowv[i] * ld, lds + ((t & ~63) + 256 * i) * 4);
+        for (int i = 0; i < PER; ++i) glds16(base + rowv[i] * ld, lds_addr_uniform(lds + ((t & ~63) + 256 * i) * 4));
     }
     __device__ __forceinline__ void load(int64_t k0, int64_t k_end) {
         if (dense(k0, k_end)) {  // uniform: unconditional 16-byte loads
@@ -309,7 +333,7 @@ __device__ __forceinline__ float4 load_quad(const float* p, int nvalid, bool vec
 
 // ------------------------------------------------------------------ the kernel body
 // NB: number of B operands sharing A (2 for the lagged covariance: B and B shifted by `lag2`).
-template <int MODE, class Cfg, int NB, bool VEC, class Epi>
+template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
 __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, int64_t lag2, const GemmDims& d,
                                            int tile_m, int tile_n, int64_t k_begin, int64_t k_end, float* lds,
                                            Epi& epi) {
@@ -335,10 +359,10 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[b][i][j][e] = 0.f;
 
-    MMajorStage<TM, KB, VEC> am;
-    KMajorStage<TM, KB, VEC> ak;
-    MMajorStage<TN, KB, VEC> bm;
-    KMajorStage<TN, KB, VEC> bk[NB];
+    MMajorStage<TM, KB, VEC, GATHER> am;
+    KMajorStage<TM, KB, VEC, GATHER> ak;
+    MMajorStage<TN, KB, VEC, GATHER> bm;
+    KMajorStage<TN, KB, VEC, GATHER> bk[NB];
     if constexpr (A_MM) am.init(A, m0, d.M, t);
     else ak.init(A, m0, d.M, t);
     if constexpr (B_MM) bm.init(B, n0, d.N, t);
@@ -444,36 +468,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 
     const int64_t nst = (k_end - k_begin + KB - 1) / KB;
     DCV_STAMP_AT(0);
-    if (nst > 0) {
-        resolve_stage(k_begin);
-        const bool dn = stage_dense(k_begin);
-        if (dn) glds_stage(k_begin, lds);
-        else load_stage(k_begin);
-        if (nst > 1) resolve_stage(k_begin + KB);
-        if (!dn) store_stage(lds);
-    }
-    stage_fence();
-    DCV_STAMP_AT(1);
     constexpr int G = KB / 8;
-    for (int64_t st = 0; st < nst; ++st) {
-        const float* cur = lds + (st & 1) * STAGE;
-        float* nxt = lds + ((st + 1) & 1) * STAGE;
-#ifdef DCV_ABL_NOLOAD
-        const bool more = false;
-#else
-        const bool more = st + 1 < nst;
-#endif
-        const int64_t k1 = k_begin + (st + 1) * KB;
-        const bool dn = more && stage_dense(k1);
-        if (more) {
-            // next stage: straight into the other LDS buffer (DMA) or into registers; either way
-            // in flight during this stage's MFMA phase
-            if (dn) glds_stage(k1, nxt);
-            else load_stage(k1);
-            if (st + 2 < nst) resolve_stage(k1 + KB);  // row indices one stage further ahead
-        }
+    auto compute_stage = [&](const float* cur) {
         const float* la = cur;
         const float* lb = cur + A_SZ;
+#ifndef DCV_NO_FRAG_DBUF
         // fragments double buffered in registers: group g+1 is read while group g feeds the MFMAs
         Frags f0, f1;
         read_frags(f0, la, lb, 0);
@@ -486,10 +485,65 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 mfma_group(f1);
             }
         }
-        if (more && !dn) store_stage(nxt);
-#ifndef DCV_ABL_NOBARRIER
-        stage_fence();
+#else
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            Frags f0;
+            read_frags(f0, la, lb, g);
+            mfma_group(f0);
+        }
 #endif
+    };
+    // Two separate main loops.  A workgroup whose every stage is fully in range (the common case)
+    // runs the pure LDS-DMA loop: no staging registers are live in it, so the compiler has no reason
+    // to wait on the vector-memory counter inside the MFMA phase.  Ragged workgroups (edge tiles, a
+    // contraction range that is not a multiple of KB, scalar loads, covariance shift) run the
+    // register-staged loop.
+    const bool all_dense = nst > 0 && stage_dense(k_begin) && ((k_end - k_begin) % KB == 0);
+    if (all_dense) {
+        resolve_stage(k_begin);
+        glds_stage(k_begin, lds);
+        if (nst > 1) resolve_stage(k_begin + KB);
+        stage_fence();
+        DCV_STAMP_AT(1);
+        for (int64_t st = 0; st < nst; ++st) {
+            const float* cur = lds + (st & 1) * STAGE;
+            float* nxt = lds + ((st + 1) & 1) * STAGE;
+#ifdef DCV_ABL_NOLOAD
+            const bool more = false;
+#else
+            const bool more = st + 1 < nst;
+#endif
+            if (more) {
+                glds_stage(k_begin + (st + 1) * KB, nxt);   // in flight during this stage's MFMA phase
+                if (st + 2 < nst) resolve_stage(k_begin + (st + 2) * KB);
+            }
+            compute_stage(cur);
+#ifndef DCV_ABL_NOBARRIER
+            stage_fence();
+#endif
+        }
+    } else {
+        if (nst > 0) {
+            resolve_stage(k_begin);
+            load_stage(k_begin);
+            if (nst > 1) resolve_stage(k_begin + KB);
+            store_stage(lds);
+        }
+        __syncthreads();
+        DCV_STAMP_AT(1);
+        for (int64_t st = 0; st < nst; ++st) {
+            const float* cur = lds + (st & 1) * STAGE;
+            float* nxt = lds + ((st + 1) & 1) * STAGE;
+            const bool more = st + 1 < nst;
+            if (more) {
+                load_stage(k_begin + (st + 1) * KB);   // into registers, in flight during the MFMA phase
+                if (st + 2 < nst) resolve_stage(k_begin + (st + 2) * KB);
+            }
+            compute_stage(cur);
+            if (more) store_stage(nxt);
+            __syncthreads();
+        }
     }
 #ifdef DCV_ABL_NOEPI
     {   // keep every accumulator live (no dead-code elimination of the MFMAs), then skip the epilogue
@@ -515,24 +569,17 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // activation gradient), out_ptr() says where a segment goes; when Epi::kColSum the per-column
     // sums of the stored values over the tile's rows go to epi.colsum(tile_m, col, sum) (bias
     // gradients for free).
-    constexpr bool kStaged = (NB == 1) && (2 * STAGE >= TM * TN);
+    // When the stage buffers are smaller than the tile (KB = 16) the tile goes through in EPASS row
+    // blocks, each written by the waves that own those rows.
+    constexpr int EPASS = (TM * TN + 2 * STAGE - 1) / (2 * STAGE);
+    constexpr int RP = TM / (EPASS > 0 ? EPASS : 1);   // rows per pass
+    constexpr bool kStaged = (NB == 1) && (EPASS <= 2) && (TM % EPASS == 0) && (RP % (FM * 32) == 0) && (RP * TN <= 2 * STAGE);
     DCV_STAMP_AT(2);
     if constexpr (kStaged) {
-        float* tile = lds;  // [TM][TN]
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int c = wn + j * 32 + (lane & 31);
-                const int rb = wm + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) tile[(rb + (e & 3) + 8 * (e >> 2)) * TN + c] = acc[0][i][j][e];
-            }
-        __syncthreads();
-        DCV_STAMP_AT(3);
+        float* tile = lds;  // [RP][TN]
         constexpr int C4 = TN / 4;           // 16-byte segments per row
-        constexpr int RPP = 256 / C4;        // rows per pass
-        constexpr int NQ = TM / RPP;         // row segments per thread
+        constexpr int RPP = 256 / C4;        // rows per pass of the store loop
+        constexpr int NQ = RP / RPP;         // row segments per thread and epilogue pass
         const int c4 = t % C4, r0 = t / C4;
         const int64_t col = n0 + c4 * 4;
         const int64_t left = d.N - col;
@@ -548,38 +595,56 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         static_assert(NQ % EQ == 0, "epilogue chunking");
         float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int qc = 0; qc < NQ; qc += EQ) {
-            float4 v[EQ], side[Epi::kSide ? EQ : 1];
-            if constexpr (Epi::kSide) {
+        for (int ep = 0; ep < EPASS; ++ep) {
+            if (ep > 0) __syncthreads();   // previous pass fully read
+            if (wm / RP == ep) {
 #pragma unroll
-                for (int q = 0; q < EQ; ++q) {
-                    const int64_t row = m0 + r0 + (qc + q) * RPP;
-                    if (fast) side[q] = *reinterpret_cast<const float4*>(epi.side_ptr(row, col));
-                    else side[q] = (row < d.M && nvalid > 0) ? load_quad(epi.side_ptr(row, col), nvalid, epi.vec) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) {
+                        const int c = wn + j * 32 + (lane & 31);
+                        const int rb = wm - ep * RP + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) tile[(rb + (e & 3) + 8 * (e >> 2)) * TN + c] = acc[0][i][j][e];
+                    }
             }
+            __syncthreads();
+            if (ep == 0) DCV_STAMP_AT(3);
+            const int64_t mbase = m0 + ep * RP;
 #pragma unroll
-            for (int q = 0; q < EQ; ++q) v[q] = *reinterpret_cast<const float4*>(tile + (r0 + (qc + q) * RPP) * TN + c4 * 4);
-            epi.template transform<EQ>(v, side, cc);
-            if (fast) {
+            for (int qc = 0; qc < NQ; qc += EQ) {
+                float4 v[EQ], side[Epi::kSide ? EQ : 1];
+                if constexpr (Epi::kSide) {
 #pragma unroll
-                for (int q = 0; q < EQ; ++q) {
-                    *reinterpret_cast<float4*>(epi.out_ptr(0, m0 + r0 + (qc + q) * RPP, col)) = v[q];
-                    if constexpr (Epi::kColSum) {
-                        cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w;
+                    for (int q = 0; q < EQ; ++q) {
+                        const int64_t row = mbase + r0 + (qc + q) * RPP;
+                        if (fast) side[q] = *reinterpret_cast<const float4*>(epi.side_ptr(row, col));
+                        else side[q] = (row < d.M && nvalid > 0) ? load_quad(epi.side_ptr(row, col), nvalid, epi.vec) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
                 }
-            } else {
 #pragma unroll
-                for (int q = 0; q < EQ; ++q) {
-                    const int64_t row = m0 + r0 + (qc + q) * RPP;
-                    if (row < d.M && nvalid > 0) {
-                        store_quad(epi.out_ptr(0, row, col), v[q], nvalid, epi.vec);
+                for (int q = 0; q < EQ; ++q) v[q] = *reinterpret_cast<const float4*>(tile + (r0 + (qc + q) * RPP) * TN + c4 * 4);
+                epi.template transform<EQ>(v, side, cc);
+                if (fast) {
+#pragma unroll
+                    for (int q = 0; q < EQ; ++q) {
+                        *reinterpret_cast<float4*>(epi.out_ptr(0, mbase + r0 + (qc + q) * RPP, col)) = v[q];
                         if constexpr (Epi::kColSum) {
-                            cs.x += v[q].x;
-                            if (nvalid > 1) cs.y += v[q].y;
-                            if (nvalid > 2) cs.z += v[q].z;
-                            if (nvalid > 3) cs.w += v[q].w;
+                            cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < EQ; ++q) {
+                        const int64_t row = mbase + r0 + (qc + q) * RPP;
+                        if (row < d.M && nvalid > 0) {
+                            store_quad(epi.out_ptr(0, row, col), v[q], nvalid, epi.vec);
+                            if constexpr (Epi::kColSum) {
+                                cs.x += v[q].x;
+                                if (nvalid > 1) cs.y += v[q].y;
+                                if (nvalid > 2) cs.z += v[q].z;
+                                if (nvalid > 3) cs.w += v[q].w;
+                            }
                         }
                     }
                 }

@@ -127,7 +127,7 @@ inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reint
 
 // ------------------------------------------------------------------ kernels
 // grid.x = tiles_m * tiles_n (tile_n fastest), grid.z = k splits (TN only)
-template <int MODE, class Cfg, int NB, bool VEC, class Epi>
+template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
 __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     // XCD-aware block -> (tile, split) map.  Blocks b and b + 8 are observed to share an XCD (and its
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
             tile_n = tile - tile_m * d.tiles_n;
         }
     }
-    gemm_block<MODE, Cfg, NB, VEC, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
+    gemm_block<MODE, Cfg, NB, VEC, GATHER, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
 }
 
 #ifndef DCV_BIGCFG
@@ -175,11 +175,15 @@ using CfgNarrowN = TileCfg<4, 1, 1, 1, 32>;  // 128 x 32
 using CfgNarrowM = TileCfg<1, 4, 1, 1, 32>;  // 32 x 128
 using CfgCov = TileCfg<2, 2, 2, 2, 16>;      // 128 x 128, two B operands, 48 KiB LDS
 
-template <int MODE, class Cfg, int NB, bool VEC, class Epi>
+template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
 static int launch_gemm_vec(const Operand& A, const Operand& B, int64_t lag2, const GemmDims& d, int64_t splits,
                            const Epi& epi, hipStream_t s) {
+#ifdef DCV_FORCE_LDS
+    constexpr size_t lds = DCV_FORCE_LDS;   // diagnostic: limit co-residency through the LDS request
+#else
     constexpr size_t lds = gemm_lds_bytes<Cfg, NB>();
-    auto kern = gemm_kernel<MODE, Cfg, NB, VEC, Epi>;
+#endif
+    auto kern = gemm_kernel<MODE, Cfg, NB, VEC, GATHER, Epi>;
     if (lds > 64 * 1024) {
         static bool attr_set = false;  // per instantiation
         if (!attr_set) {
@@ -218,8 +222,10 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
     // 16-byte loads: aligned operands; contraction-contiguous (MMAJOR) operands also need K % 4 == 0
     constexpr bool A_MM = (MODE == kNT || MODE == kNN), B_MM = (MODE == kNT);
     const bool vec = A.vec_ok && B.vec_ok && (!A_MM || K % 4 == 0) && (!B_MM || K % 4 == 0) && (MODE != kTN || d.k_chunk % 1 == 0);
-    if (vec) return launch_gemm_vec<MODE, Cfg, NB, true, Epi>(A, B, lag2, d, splits, epi, s);
-    return launch_gemm_vec<MODE, Cfg, NB, false, Epi>(A, B, lag2, d, splits, epi, s);
+    const bool gather = A.rows.idx != nullptr || B.rows.idx != nullptr;
+    if (vec && !gather) return launch_gemm_vec<MODE, Cfg, NB, true, false, Epi>(A, B, lag2, d, splits, epi, s);
+    if (vec) return launch_gemm_vec<MODE, Cfg, NB, true, true, Epi>(A, B, lag2, d, splits, epi, s);
+    return launch_gemm_vec<MODE, Cfg, NB, false, true, Epi>(A, B, lag2, d, splits, epi, s);   // scalar loads: gather-capable form
 }
 
 // Picks the tile shape from the output extents.  Row-parallel products (NT / NN) fall back to

@@ -442,7 +442,7 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
     double s = 0.0;
     for (int64_t r = r0; r < r1; ++r) {
         const float* y = Y + r * ldy;
-        const float* x = Xn + rows(r) * ldx;
+        const float* x = Xn + rows.template get<true>(r) * ldx;
         for (int c = t; c < F; c += 256) {
             const float e = (y[c] - x[c]) * range[c];
             s += (double)e * (double)e;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void ae_dY_kernel(const float* __restrict__ Y,
         const int64_t r = i / F;
         const int c = (int)(i - r * F);
         const float y = Y[r * ldy + c];
-        const float x = Xn[rows(r) * ldx + c];
+        const float x = Xn[rows.template get<true>(r) * ldx + c];
         const float rg = range[c];
         dZ[r * ldz + c] = scale * (y - x) * rg * rg * act_grad_from_out(act, y);
     }

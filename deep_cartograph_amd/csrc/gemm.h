@@ -36,11 +36,18 @@ __device__ unsigned long long g_stamp[8 * 8192];
         if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.z == 0)                           \
             g_stamp[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memtime();                   \
     } while (0)
+#define DCV_STAMP_RT(slot)                                                                      \
+    do {                                                                                        \
+        if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.z == 0)                           \
+            g_stamp[blockIdx.x * 8 + (slot)] = __builtin_amdgcn_s_memrealtime();               \
+    } while (0)
 #else
 #define DCV_STAMP_AT(slot) do {} while (0)
+#define DCV_STAMP_RT(slot) do {} while (0)
 #endif
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
 enum GemmMode { kNT = 0, kNN = 1, kTN = 2 };
 
@@ -81,9 +88,12 @@ struct GemmDims {
     int xcd_remap;    // XCD-aware block -> tile map enabled (launch-time decision)
 };
 
-template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_>
+// NBUF: LDS stage buffers of the pure-DMA main loop (a ring: NBUF-1 stages in flight ahead of the
+// one being multiplied); the register-staged loop always double-buffers in the first two.
+template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_, int NBUF_ = 2>
 struct TileCfg {
-    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, FM = FM_, FN = FN_, KB = KB_;
+    static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, FM = FM_, FN = FN_, KB = KB_, NBUF = NBUF_;
+    static_assert(NBUF >= 2 && NBUF <= 8, "NBUF");
     static constexpr int TM = WAVES_M * FM * 32;
     static constexpr int TN = WAVES_N * FN * 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -110,7 +120,7 @@ __device__ __forceinline__ int mmajor_off(int row, int chunk) {
 // Issued through inline asm on purpose: hipcc treats the builtin form as an LDS write it must
 // order against later ds_reads and waits vmcnt(0) right after issuing it, which serialises the
 // DMA with the MFMA phase.  The asm form is outside the compiler's vmcnt bookkeeping; completion
-// is awaited explicitly (stage_fence: s_waitcnt vmcnt(0) + barrier) before the image is read.
+// is awaited explicitly (asm s_waitcnt vmcnt(N), then the workgroup barrier) before the image is read.
 // M0 carries the wave-uniform LDS byte address; it is compiler-reserved, so it is saved / restored
 // inside the same statement (cdna_hip_programming.md section 5.7).
 __device__ __forceinline__ void glds16(const float* gsrc, unsigned lds_wave_addr) {
@@ -131,6 +141,50 @@ __device__ __forceinline__ unsigned lds_addr_uniform(const float* p) {
     return __builtin_amdgcn_readfirstlane(a);
 }
 
+// Batched form for tiles whose rows are an affine function of the row index (no gather): wave-uniform
+// 64-bit base in SGPRs + one constant 32-bit byte offset per unit in a VGPR, so a stage costs no
+// vector-ALU instruction at all (the issue slots of a SIMD are shared with the co-resident workgroup's
+// MFMA stream, and address arithmetic there was measured at ~2500 cycles per stage).  lds0 is the
+// wave's LDS byte address for unit 0; unit i lands 4096 bytes further.  The leading s_nop covers a
+// base that the compiler produced with v_readfirstlane (5 wait states before a VMEM read of it).
+template <int PER>
+__device__ __forceinline__ void glds16_batch(const float* base, const unsigned (&voff)[PER], unsigned lds0) {
+    static_assert(PER == 1 || PER == 2 || PER == 4, "units per thread");
+    unsigned keep;
+    if constexpr (PER == 1) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_nop 3\n\t"
+            "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "s"(base), "s"(lds0)
+            : "memory");
+    } else if constexpr (PER == 2) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_nop 3\n\t"
+            "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+            "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "s"(base), "s"(lds0), "s"(lds0 + 4096u)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_nop 3\n\t"
+            "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+            "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+            "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5\n\t"
+            "s_mov_b32 m0, %9\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(base), "s"(lds0), "s"(lds0 + 4096u),
+              "s"(lds0 + 8192u), "s"(lds0 + 12288u)
+            : "memory");
+    }
+}
+// largest leading dimension the 32-bit unit offsets of the batched form cover (128 rows * ld * 4 bytes < 2^32)
+constexpr int64_t kMaxAffineLd = (int64_t)1 << 22;
+
 // MMAJOR tile [T][KB]: unit u = t + 256*i -> row = u / CPR, slot = u % CPR.  A thread's rows are
 // the same in every stage, so their base pointers are resolved once.
 template <int T, int KB, bool VEC, bool GATHER>
@@ -142,20 +196,31 @@ struct MMajorStage {
     static_assert(256 % CPR == 0 && ((256 / CPR) / RPBR) % CPR == 0, "swizzle must not depend on the unit index");
     float4 r[PER];
     const float* src[PER];  // &A[row][logical chunk * 4] or null when the row is out of range
+    unsigned voff[PER];     // byte offset of unit i from the tile's first row (affine tiles)
     int kofs;               // logical chunk * 4
     bool all_rows;          // every row of the tile is in range (workgroup-uniform)
+    bool affine;            // the tile's rows are row0 + m: no gather, not astride the x_t / x_lag seam
 
     __device__ __forceinline__ void init(const Operand& op, int64_t m0, int64_t m_end, int t) {
         const int row0 = t / CPR;
         kofs = ((t % CPR) ^ ((row0 / RPBR) % CPR)) * 4;
         all_rows = (UNITS % 256 == 0) && (m0 + T <= m_end);
+        affine = !GATHER && op.ld < kMaxAffineLd && (op.rows.half <= 0 || m0 >= op.rows.half || m0 + T <= op.rows.half);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int u = t + 256 * i;
             const int64_t m = m0 + u / CPR;
             const bool ok = (UNITS % 256 == 0 || u < UNITS) && m < m_end;
             src[i] = ok ? op.p + op.rows.template get<GATHER>(m) * op.ld + kofs : nullptr;
+            voff[i] = (unsigned)(((int64_t)(u / CPR) * op.ld + kofs) * 4);
         }
+    }
+    // wave-uniform base of the affine form: first row of the tile, contraction offset k0
+    __device__ __forceinline__ const float* tile_base(const Operand& op, int64_t m0, int64_t k0) const {
+        return op.p + op.rows.template get<false>(m0) * op.ld + k0;
+    }
+    __device__ __forceinline__ void glds_affine(const float* base, unsigned lds0) const {
+        if constexpr (UNITS % 256 == 0 && (PER == 1 || PER == 2 || PER == 4)) glds16_batch<PER>(base, voff, lds0);
     }
     __device__ __forceinline__ bool dense(int64_t k0, int64_t k_end) const { return VEC && all_rows && k0 + KB <= k_end; }
     __device__ __forceinline__ void glds(int64_t k0, float* lds, int t) const {
@@ -211,6 +276,8 @@ struct KMajorStage {
     int ncol;           // how many of the 4 columns are in range (0..4)
     bool has_shift;
     bool all_cols;      // every column of the tile in range, 16-byte loads, no shift (workgroup-uniform)
+    bool affine;        // no gather and a leading dimension the 32-bit unit offsets cover
+    unsigned voff[PER]; // byte offset of unit i from (first row of the stage, first column of the tile)
 
     __device__ __forceinline__ void init(const Operand& op, int64_t c0, int64_t c_end, int t) {
         const int64_t col = c0 + (t % C4) * 4;
@@ -227,7 +294,23 @@ struct KMajorStage {
             if (ncol > 3) sh.w = op.shift[col + 3];
         }
         all_cols = VEC && (UNITS % 256 == 0) && !has_shift && (c0 + T <= c_end);
+        affine = !GATHER && op.ld < kMaxAffineLd;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int u = t + 256 * i;
+            voff[i] = (unsigned)(((int64_t)(u / C4) * op.ld + (u % C4) * 4) * 4);
+        }
         okmask = 0;
+    }
+    // affine form: the KB rows of the stage at k0 must be consecutive matrix rows
+    __device__ __forceinline__ static bool stage_affine(const Operand& op, int64_t k0) {
+        return op.rows.half <= 0 || k0 >= op.rows.half || k0 + KB <= op.rows.half;
+    }
+    __device__ __forceinline__ static const float* stage_base(const Operand& op, int64_t k0, int64_t row_off, int64_t c0) {
+        return op.p + (op.rows.template get<false>(k0) + row_off) * op.ld + c0;
+    }
+    __device__ __forceinline__ void glds_affine(const float* base, unsigned lds0) const {
+        if constexpr (UNITS % 256 == 0 && (PER == 1 || PER == 2 || PER == 4)) glds16_batch<PER>(base, voff, lds0);
     }
     __device__ __forceinline__ void resolve(const Operand& op, int64_t k0, int64_t k_end, int64_t row_off, int t) {
 #pragma unroll
@@ -288,10 +371,10 @@ struct KMajorStage {
 // ------------------------------------------------------------------ fragments
 // MMAJOR fragment of the 32 rows starting at `rb`, k-group g: 4 k values per lane.
 template <int KB>
-__device__ __forceinline__ float4 frag_mmajor(const float* lds, int rb, int g, int lane) {
+__device__ __forceinline__ v4f frag_mmajor(const float* lds, int rb, int g, int lane) {
     const int row = rb + (lane & 31);
     const int chunk = 2 * g + (lane >> 5);
-    return *reinterpret_cast<const float4*>(lds + mmajor_off<KB>(row, chunk));
+    return *reinterpret_cast<const v4f*>(lds + mmajor_off<KB>(row, chunk));
 }
 // KMAJOR fragment of the 32 columns starting at `cb`, k-group g, step s.
 template <int T>
@@ -329,6 +412,21 @@ __device__ __forceinline__ float4 load_quad(const float* p, int nvalid, bool vec
         if (nvalid > 3) v.w = p[3];
     }
     return v;
+}
+
+// s_waitcnt vmcnt(N) through asm: the LDS-DMA instructions it counts are asm too (see glds16)
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most min(MAXY, younger) stages of GL instructions each are still in flight
+template <int MAXY, int GL>
+__device__ __forceinline__ void vm_wait_younger(int64_t younger) {
+    if constexpr (MAXY == 0) vm_wait<0>();
+    else {
+        if (younger >= MAXY) vm_wait<MAXY * GL>();
+        else vm_wait_younger<MAXY - 1, GL>(younger);
+    }
 }
 
 // ------------------------------------------------------------------ the kernel body
@@ -392,14 +490,51 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         }
         return ok;
     };
-    auto glds_stage = [&](int64_t k0, float* buf) {
-        if constexpr (A_MM) am.glds(k0, buf, t);
-        else ak.glds(buf, t);
-        if constexpr (B_MM) bm.glds(k0, buf + A_SZ, t);
-        else {
-            bk[0].glds(buf + A_SZ, t);
-            if constexpr (NB == 2) bk[1].glds(buf + A_SZ + B_SZ, t);
+    // pure-DMA issue of the stage at k0 into ring buffer `buf`
+    const unsigned ldsw = lds_addr_uniform(lds + (t & ~63) * 4);   // this wave's unit-0 slot of buffer 0
+    auto glds_stage = [&](int64_t k0, int buf, int part = 3) {   // part: 1 = A operand, 2 = B operand(s)
+        if constexpr (GATHER) {   // per-thread 64-bit source pointers
+            float* b = lds + buf * STAGE;
+            if (part & 1) {
+                resolve_stage(k0);
+                if constexpr (A_MM) am.glds(k0, b, t);
+                else ak.glds(b, t);
+            }
+            if (part & 2) {
+                if constexpr (B_MM) bm.glds(k0, b + A_SZ, t);
+                else {
+                    bk[0].glds(b + A_SZ, t);
+                    if constexpr (NB == 2) bk[1].glds(b + A_SZ + B_SZ, t);
+                }
+            }
+        } else {                  // affine tiles: uniform base + constant unit offsets, no vector ALU
+            const unsigned l0 = ldsw + (unsigned)(buf * STAGE) * 4u;
+            if (part & 1) {
+                if constexpr (A_MM) am.glds_affine(am.tile_base(A, m0, k0), l0);
+                else ak.glds_affine(ak.stage_base(A, k0, 0, m0), l0);
+            }
+            if (part & 2) {
+                if constexpr (B_MM) bm.glds_affine(bm.tile_base(B, n0, k0), l0 + A_SZ * 4u);
+                else {
+                    bk[0].glds_affine(bk[0].stage_base(B, k0, 0, n0), l0 + A_SZ * 4u);
+                    if constexpr (NB == 2) bk[1].glds_affine(bk[1].stage_base(B, k0, lag2, n0), l0 + (A_SZ + B_SZ) * 4u);
+                }
+            }
         }
+    };
+    // workgroup-uniform: every stage of [k_begin, k_end) can take the affine form
+    auto affine_all = [&]() -> bool {
+        if constexpr (GATHER) return true;
+        auto seam_ok = [&](const Operand& op) {   // KMAJOR: the x_t / x_lag seam falls on a stage boundary
+            const int64_t h = op.rows.half;
+            return h <= 0 || k_begin >= h || k_end <= h || ((h - k_begin) % KB == 0);
+        };
+        bool ok;
+        if constexpr (A_MM) ok = am.affine;
+        else ok = ak.affine && seam_ok(A);
+        if constexpr (B_MM) ok = ok && bm.affine;
+        else ok = ok && bk[0].affine && seam_ok(B);
+        return ok;
     };
     auto load_stage = [&](int64_t k0) {
         if constexpr (A_MM) am.load(k0, k_end);
@@ -419,23 +554,16 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             if constexpr (NB == 2) bk[1].store(buf + A_SZ + B_SZ, t);
         }
     };
-    // every LDS-DMA of this wave has landed; then the workgroup barrier publishes the stage
-    auto stage_fence = [&]() {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
     // fragments of one k-group (4 MFMA steps): registers av[i][s], bv[b][j][s]
     struct Frags {
-        float a[FM][4];
-        float b[NB][FN][4];
+        v4f a[FM];
+        v4f b[NB][FN];
     };
     auto read_frags = [&](Frags& f, const float* la, const float* lb, int g) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             if constexpr (A_MM) {
-                const float4 v = frag_mmajor<KB>(la, wm + i * 32, g, lane);
-                f.a[i][0] = v.x; f.a[i][1] = v.y; f.a[i][2] = v.z; f.a[i][3] = v.w;
+                f.a[i] = frag_mmajor<KB>(la, wm + i * 32, g, lane);
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) f.a[i][s] = frag_kmajor<TM>(la, wm + i * 32, g, s, lane);
@@ -446,13 +574,36 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
                 if constexpr (B_MM) {
-                    const float4 v = frag_mmajor<KB>(lb, wn + j * 32, g, lane);
-                    f.b[b][j][0] = v.x; f.b[b][j][1] = v.y; f.b[b][j][2] = v.z; f.b[b][j][3] = v.w;
+                    f.b[b][j] = frag_mmajor<KB>(lb, wn + j * 32, g, lane);
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) f.b[b][j][s] = frag_kmajor<TN>(lb + b * B_SZ, wn + j * 32, g, s, lane);
                 }
             }
+    };
+    // Makes the 128-bit fragment registers opaque right before their MFMA group: the ds_read_b128 that
+    // produced them must stay whole (hipcc otherwise scalarises a vector load whose lanes are consumed
+    // one MFMA step at a time once the loop is rotated across the stage boundary).
+    auto pin_frags = [&](Frags& f) {
+        if constexpr (A_MM) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asm volatile("" : "+v"(f.a[i]));
+        }
+        if constexpr (B_MM) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(f.b[b][j]));
+        }
+    };
+    auto mfma_step = [&](const Frags& f, int s) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[b][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[b][j][s], acc[b][i][j], 0, 0, 0);
     };
     auto mfma_group = [&](const Frags& f) {
 #pragma unroll
@@ -468,6 +619,10 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 
     const int64_t nst = (k_end - k_begin + KB - 1) / KB;
     DCV_STAMP_AT(0);
+#ifdef DCV_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 8192 && blockIdx.z == 0)
+        g_stamp[blockIdx.x * 8 + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);
+#endif
     constexpr int G = KB / 8;
     auto compute_stage = [&](const float* cur) {
         const float* la = cur;
@@ -499,30 +654,84 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // to wait on the vector-memory counter inside the MFMA phase.  Ragged workgroups (edge tiles, a
     // contraction range that is not a multiple of KB, scalar loads, covariance shift) run the
     // register-staged loop.
-    const bool all_dense = nst > 0 && stage_dense(k_begin) && ((k_end - k_begin) % KB == 0);
+    const bool all_dense = nst > 0 && stage_dense(k_begin) && ((k_end - k_begin) % KB == 0) && affine_all();
     if (all_dense) {
-        resolve_stage(k_begin);
-        glds_stage(k_begin, lds);
-        if (nst > 1) resolve_stage(k_begin + KB);
-        stage_fence();
+        // Ring of NBUF stage buffers, rotated by one fragment group.  At the boundary between stages st
+        // and st+1 every wave waits for its own DMA of stage st+1, the barrier publishes that stage and
+        // retires buffer st % NBUF (all its fragment reads have returned), the DMA of stage st+NBUF is
+        // issued into it (scalar instructions only) and the first fragments of stage st+1 are read --
+        // and only then are the MFMAs of the LAST group of stage st issued, from registers: they cover
+        // the barrier skew, the DMA issue and the LDS latency, so the matrix pipe does not drain at
+        // stage boundaries even with one wave per SIMD.
+        constexpr int NBUF = Cfg::NBUF;
+        constexpr int GL = (A_MM ? MMajorStage<TM, KB, VEC, GATHER>::PER : KMajorStage<TM, KB, VEC, GATHER>::PER) +
+                           NB * (B_MM ? MMajorStage<TN, KB, VEC, GATHER>::PER : KMajorStage<TN, KB, VEC, GATHER>::PER);  // DMA instructions per thread and stage
+        static_assert((NBUF - 2) * GL <= 63, "vmcnt range");
+        static_assert(G % 2 == 0, "fragment double buffer parity");
+#pragma unroll
+        for (int s = 0; s < NBUF - 1; ++s)
+            if (s < nst) glds_stage(k_begin + s * KB, s);
+        // boundary "-1 -> 0": stage 0 landed and published; every buffer is still free
+        vm_wait_younger<NBUF - 2, GL>(nst - 1);
+        __syncthreads();
+#ifndef DCV_ABL_NOLOAD
+        if (NBUF - 1 < nst) glds_stage(k_begin + (NBUF - 1) * KB, NBUF - 1);
+#endif
         DCV_STAMP_AT(1);
+        DCV_STAMP_RT(5);
+        Frags f0, f1;
+        read_frags(f0, lds, lds + A_SZ, 0);
+        int cur_buf = 0;
         for (int64_t st = 0; st < nst; ++st) {
-            const float* cur = lds + (st & 1) * STAGE;
-            float* nxt = lds + ((st + 1) & 1) * STAGE;
-#ifdef DCV_ABL_NOLOAD
-            const bool more = false;
-#else
-            const bool more = st + 1 < nst;
-#endif
-            if (more) {
-                glds_stage(k_begin + (st + 1) * KB, nxt);   // in flight during this stage's MFMA phase
-                if (st + 2 < nst) resolve_stage(k_begin + (st + 2) * KB);
-            }
-            compute_stage(cur);
+            const float* la = lds + cur_buf * STAGE;
+            const float* lb = la + A_SZ;
+            const int nxt_buf = cur_buf + 1 == NBUF ? 0 : cur_buf + 1;
+#pragma unroll
+            for (int g = 0; g < G; g += 2) {
+                read_frags(f1, la, lb, g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                pin_frags(f0);
+                mfma_group(f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (g + 2 < G) {
+                    read_frags(f0, la, lb, g + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pin_frags(f1);
+                    mfma_group(f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {   // stage boundary, interleaved with the last group's MFMAs
+                    // One straight-line path (only the DMA issue is conditional): the last stage waits,
+                    // synchronises and reads fragments of a stale buffer for nothing, which is cheaper
+                    // than the accumulator copies hipcc generates when MFMAs sit on divergent paths.
+                    vm_wait_younger<NBUF - 2, GL>(nst - 2 - st);
 #ifndef DCV_ABL_NOBARRIER
-            stage_fence();
+                    __syncthreads();
 #endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    pin_frags(f1);
+                    mfma_step(f1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef DCV_ABL_NOLOAD
+                    if (st + NBUF < nst) glds_stage(k_begin + (st + NBUF) * KB, cur_buf, 1);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(f1, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+#ifndef DCV_ABL_NOLOAD
+                    if (st + NBUF < nst) glds_stage(k_begin + (st + NBUF) * KB, cur_buf, 2);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(f1, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_frags(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_step(f1, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            cur_buf = nxt_buf;
         }
+        __syncthreads();   // last stage fully read before the epilogue reuses the buffers
     } else {
         if (nst > 0) {
             resolve_stage(k_begin);
@@ -532,6 +741,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         }
         __syncthreads();
         DCV_STAMP_AT(1);
+        DCV_STAMP_RT(5);
         for (int64_t st = 0; st < nst; ++st) {
             const float* cur = lds + (st & 1) * STAGE;
             float* nxt = lds + ((st + 1) & 1) * STAGE;
@@ -544,6 +754,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             if (more) store_stage(nxt);
             __syncthreads();
         }
+        // Compiler-visible vmcnt(0): hipcc's wait-count dataflow is path-insensitive and otherwise believes the
+        // last iteration's register loads may still be pending where this branch re-joins the pure-DMA one, and
+        // then protects the first fragment register written in EVERY pure-DMA stage with an s_waitcnt vmcnt(0)
+        // (which serialises the LDS-DMA of the next stage against the MFMA phase).
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
 #ifdef DCV_ABL_NOEPI
     {   // keep every accumulator live (no dead-code elimination of the MFMAs), then skip the epilogue
@@ -571,10 +786,12 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // gradients for free).
     // When the stage buffers are smaller than the tile (KB = 16) the tile goes through in EPASS row
     // blocks, each written by the waves that own those rows.
-    constexpr int EPASS = (TM * TN + 2 * STAGE - 1) / (2 * STAGE);
+    constexpr int LDSF = Cfg::NBUF * STAGE;   // floats of LDS the kernel owns
+    constexpr int EPASS = (TM * TN + LDSF - 1) / LDSF;
     constexpr int RP = TM / (EPASS > 0 ? EPASS : 1);   // rows per pass
-    constexpr bool kStaged = (NB == 1) && (EPASS <= 2) && (TM % EPASS == 0) && (RP % (FM * 32) == 0) && (RP * TN <= 2 * STAGE);
+    constexpr bool kStaged = (NB == 1) && (EPASS <= 2) && (TM % EPASS == 0) && (RP % (FM * 32) == 0) && (RP * TN <= LDSF);
     DCV_STAMP_AT(2);
+    DCV_STAMP_RT(6);
     if constexpr (kStaged) {
         float* tile = lds;  // [RP][TN]
         constexpr int C4 = TN / 4;           // 16-byte segments per row
@@ -684,7 +901,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 
 template <class Cfg, int NB>
 constexpr size_t gemm_lds_bytes() {
-    return (size_t)2 * (Cfg::TM * Cfg::KB + NB * Cfg::TN * Cfg::KB) * sizeof(float);
+    return (size_t)Cfg::NBUF * (Cfg::TM * Cfg::KB + NB * Cfg::TN * Cfg::KB) * sizeof(float);
 }
 
 }  // namespace dcv

@@ -31,15 +31,37 @@ static void dump_stamps(const char* what, int nblk) {
     std::vector<unsigned long long> h(8 * 8192);
     CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(dcv::g_stamp), h.size() * 8));
     if (nblk > 8192) nblk = 8192;
+    if (const char* dir = getenv("DCV_STAMP_DUMP")) {
+        char path[512];
+        snprintf(path, sizeof path, "%s/stamps_%s.bin", dir, what);
+        for (char* c = path + strlen(dir); *c; ++c) if (*c == ' ') *c = '_';
+        if (FILE* f = fopen(path, "wb")) { fwrite(h.data(), 8, (size_t)nblk * 8, f); fclose(f); }
+    }
     double ph[4] = {0, 0, 0, 0};
+    double clk = 0;
     unsigned long long t0 = ~0ull, t1 = 0;
     for (int b = 0; b < nblk; ++b) {
         for (int p = 0; p < 4; ++p) ph[p] += (double)(h[b * 8 + p + 1] - h[b * 8 + p]);
+        clk += (double)(h[b * 8 + 2] - h[b * 8 + 1]) / (double)(h[b * 8 + 6] - h[b * 8 + 5]) * 0.1;  // GHz (s_memrealtime = 100 MHz)
         if (h[b * 8] < t0) t0 = h[b * 8];
         if (h[b * 8 + 4] > t1) t1 = h[b * 8 + 4];
     }
-    printf("   %s stamps (cycles, mean/WG over %d WGs): prologue %.0f  mainloop %.0f  lds-transpose %.0f  store-loop %.0f   | kernel span %.0f\n",
-           what, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, (double)(t1 - t0));
+    printf("   %s stamps (cycles, mean/WG over %d WGs): prologue %.0f  mainloop %.0f  lds-transpose %.0f  store-loop %.0f | in-kernel clock %.3f GHz\n",
+           what, nblk, ph[0] / nblk, ph[1] / nblk, ph[2] / nblk, ph[3] / nblk, clk / nblk);
+    // s_memtime is per XCD: spans per XCD (block b runs on XCD b % 8); s_memrealtime (10 ns) is chip wide
+    double xs = 0;
+    for (int x = 0; x < 8; ++x) {
+        unsigned long long a = ~0ull, z = 0;
+        for (int b = x; b < nblk; b += 8) { if (h[b * 8] < a) a = h[b * 8]; if (h[b * 8 + 4] > z) z = h[b * 8 + 4]; }
+        xs += (double)(z - a) / 8;
+    }
+    unsigned long long r0 = ~0ull, r1 = 0;
+    for (int b = 0; b < nblk; ++b) { if (h[b * 8 + 5] < r0) r0 = h[b * 8 + 5]; if (h[b * 8 + 6] > r1) r1 = h[b * 8 + 6]; }
+    int hist[16] = {0};
+    for (int b = 0; b < nblk; ++b) { int k = (int)((h[b * 8 + 5] - r0) * 16 / (r1 - r0 + 1)); hist[k]++; }
+    printf("      per-XCD span first stamp0 -> last stamp4: %.0f cycles; mainloop realtime span %.2f us; mainloop-start histogram (16 bins):", xs, (double)(r1 - r0) * 0.01);
+    for (int k = 0; k < 16; ++k) printf(" %d", hist[k]);
+    printf("\n");
 }
 #else
 static void dump_stamps(const char*, int) {}
@@ -56,10 +78,11 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dZ, (size_t)R * H1 * 4));
     CK(hipMalloc(&W2, (size_t)H2 * H1 * 4));
     CK(hipMalloc(&H2b, (size_t)R * H2 * 4));
-    CK(hipMalloc(&slab, (size_t)256 * H1 * F * 4));
+    CK(hipMalloc(&slab, (size_t)((R + 511) / 512 + 1) * H1 * F * 4));  // one slab per smallest k-chunk
     CK(hipMalloc(&bpart, (size_t)(R / 32 + 8) * H1 * 4));
     std::vector<float> h((size_t)R * F);
-    for (auto& v : h) v = (float)rand() / RAND_MAX - 0.5f;
+    const bool zeros = argc > 3 && !strcmp(argv[3], "zero");
+    for (auto& v : h) v = zeros ? 0.f : (float)rand() / RAND_MAX - 0.5f;
     CK(hipMemcpy(X, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(W1, h.data(), (size_t)H1 * F * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(W2, h.data(), (size_t)H2 * H1 * 4, hipMemcpyHostToDevice));
@@ -68,7 +91,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(H2b, h.data(), (size_t)R * H2 * 4, hipMemcpyHostToDevice));
     CK(hipMemset(Hb, 0, (size_t)R * H1 * 4));
     hipStream_t s = 0;
-    const int it = 20;
+    const int it = argc > 2 ? atoi(argv[2]) : 20;
     {   // L0 forward: [R,512] x [256,512]^T
         Operand A = make_operand(X, F, F), B = make_operand(W1, F, F);
         EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};

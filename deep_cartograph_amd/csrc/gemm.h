@@ -649,13 +649,15 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         }
 #endif
     };
-    // Two separate main loops.  A workgroup whose every stage is fully in range (the common case)
-    // runs the pure LDS-DMA loop: no staging registers are live in it, so the compiler has no reason
-    // to wait on the vector-memory counter inside the MFMA phase.  Ragged workgroups (edge tiles, a
-    // contraction range that is not a multiple of KB, scalar loads, covariance shift) run the
-    // register-staged loop.
-    const bool all_dense = nst > 0 && stage_dense(k_begin) && ((k_end - k_begin) % KB == 0) && affine_all();
-    if (all_dense) {
+    // Two main loops in sequence.  The full stages of a workgroup whose tile is fully in range (the
+    // common case) run the pure LDS-DMA loop: no staging registers are live in it, so the compiler has
+    // no reason to wait on the vector-memory counter inside the MFMA phase.  Whatever remains -- the
+    // ragged last stage of such a workgroup, or every stage of an edge tile / scalar-load / covariance
+    // shift workgroup -- runs the register-staged loop behind it.
+    const bool dense_ok = nst > 0 && stage_dense(k_begin) && affine_all();
+    const int64_t nfull = dense_ok ? (k_end - k_begin) / KB : 0;
+    if (nfull > 0) {
+        const int64_t nst = nfull;   // stages of the ring loop
         // Ring of NBUF stage buffers, rotated by one fragment group.  At the boundary between stages st
         // and st+1 every wave waits for its own DMA of stage st+1, the barrier publishes that stage and
         // retires buffer st % NBUF (all its fragment reads have returned), the DMA of stage st+NBUF is
@@ -731,34 +733,31 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             }
             cur_buf = nxt_buf;
         }
-        __syncthreads();   // last stage fully read before the epilogue reuses the buffers
+        __syncthreads();   // last stage fully read before the buffers are reused
     } else {
-        if (nst > 0) {
-            resolve_stage(k_begin);
-            load_stage(k_begin);
-            if (nst > 1) resolve_stage(k_begin + KB);
-            store_stage(lds);
-        }
-        __syncthreads();
         DCV_STAMP_AT(1);
         DCV_STAMP_RT(5);
-        for (int64_t st = 0; st < nst; ++st) {
+    }
+    const int64_t k_rem = k_begin + nfull * KB;
+    const int64_t nrem = (k_end - k_rem + KB - 1) / KB;
+    if (nrem > 0) {
+        resolve_stage(k_rem);
+        load_stage(k_rem);
+        if (nrem > 1) resolve_stage(k_rem + KB);
+        store_stage(lds);
+        __syncthreads();
+        for (int64_t st = 0; st < nrem; ++st) {
             const float* cur = lds + (st & 1) * STAGE;
             float* nxt = lds + ((st + 1) & 1) * STAGE;
-            const bool more = st + 1 < nst;
+            const bool more = st + 1 < nrem;
             if (more) {
-                load_stage(k_begin + (st + 1) * KB);   // into registers, in flight during the MFMA phase
-                if (st + 2 < nst) resolve_stage(k_begin + (st + 2) * KB);
+                load_stage(k_rem + (st + 1) * KB);   // into registers, in flight during the MFMA phase
+                if (st + 2 < nrem) resolve_stage(k_rem + (st + 2) * KB);
             }
             compute_stage(cur);
             if (more) store_stage(nxt);
             __syncthreads();
         }
-        // Compiler-visible vmcnt(0): hipcc's wait-count dataflow is path-insensitive and otherwise believes the
-        // last iteration's register loads may still be pending where this branch re-joins the pure-DMA one, and
-        // then protects the first fragment register written in EVERY pure-DMA stage with an s_waitcnt vmcnt(0)
-        // (which serialises the LDS-DMA of the next stage against the MFMA phase).
-        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
 #ifdef DCV_ABL_NOEPI
     {   // keep every accumulator live (no dead-code elimination of the MFMAs), then skip the epilogue

@@ -14,16 +14,23 @@ kt_files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
 
 
 def short(name):
+    name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d)>", r"Cfg\1\2\3\4k\5b\6", name)
     name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+)>", r"Cfg\1\2\3\4k\5", name)
     name = re.sub(r"\(.*", "", name)
     return name.replace("void ", "")[:100]
 
 
+# the counter CSV carries only the total grid size: take x/y/z from the kernel trace of the same run
+grid_xyz = {}
+for f in kt_files:
+    for r in csv.DictReader(open(f)):
+        grid_xyz[r["Dispatch_Id"]] = "x".join(str(r[k]) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z") if k in r)
+
+
 def grid_of(r):
-    if "Grid_Size" in r and r["Grid_Size"]:
-        return str(r["Grid_Size"])
-    keys = [k for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z") if k in r]
-    return "x".join(str(r[k]) for k in keys)
+    if "Grid_Size_X" in r:
+        return "x".join(str(r[k]) for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z") if k in r)
+    return grid_xyz.get(r.get("Dispatch_Id"), str(r.get("Grid_Size", "")))
 
 
 vals = defaultdict(lambda: defaultdict(list))
@@ -34,11 +41,19 @@ for f in cnt_files:
             continue
         vals[(short(k), grid_of(r))][r["Counter_Name"]].append(float(r["Counter_Value"]))
 dur = defaultdict(list)
-for f in kt_files:
+for f in ([] if cnt_files else kt_files):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if "dcv::" not in k:
             continue
+        dur[(short(k), grid_of(r))].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
+seen = set()
+for f in cnt_files:
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "dcv::" not in k or r["Dispatch_Id"] in seen:
+            continue
+        seen.add(r["Dispatch_Id"])
         dur[(short(k), grid_of(r))].append((float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) / 1e3)
 out = {}
 keys = sorted(set(vals) | set(dur), key=lambda k: -sum(dur.get(k, [0])))

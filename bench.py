@@ -43,6 +43,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--profile-level", type=int, default=1)
+    p.add_argument("--alt-batch", type=int, default=8192,
+                   help="also report (field 'secondary') the throughput at this global batch -- the size SURVEY.md 8d floated; 0 disables")
+    p.add_argument("--alt-steps", type=int, default=300)
     return p.parse_args()
 
 
@@ -101,6 +104,10 @@ def main():
     dist = None
     if world > 1 or os.environ.get("DCV_FORCE_DIST") == "1":  # the env switch exercises the collective path on one GPU
         import torch.distributed as dist  # noqa: F811
+
+        if world == 1:   # forced single-rank group: supply the rendezvous the launcher would
+            for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
+                os.environ.setdefault(k, v)
 
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -238,6 +245,49 @@ def main():
                 "all_kernels_ms": {f"layer{l}.{k}": v[1] for (l, k), v in sorted(flops.items())},
             },
         }
+    eng.close()
+    # ---- secondary: the same fit at the small global batch of SURVEY 8d (launch-latency bound; every rank runs it)
+    alt = None
+    if a.alt_batch > 0 and a.alt_batch % world == 0 and a.alt_batch != a.batch:
+        alb = a.alt_batch // world
+        a_train = int(P_local * 0.8) // alb * alb
+        a_spe = a_train // alb
+        if a_spe >= 1:
+            eng2 = hip.Mlp("deep_tica", dims, acts, max_batch=alb, lag=lag, tica_reg=1e-6, lr=a.lr)
+            eng2.set_linears(linears)
+            sv2, gv2 = eng2.stats_view(), eng2.grads_view()
+            eng2.reset_log(a.alt_steps + 64)
+
+            def alt_step(i):
+                r0 = (i % a_spe) * alb
+                if dist is None:
+                    eng2.train_step(Xn, row0=r0, batch=alb)
+                else:
+                    eng2.forward(Xn, row0=r0, batch=alb)
+                    dist.all_reduce(sv2, op=dist.ReduceOp.SUM)
+                    eng2.backward(Xn, row0=r0, batch=alb, global_batch=a.alt_batch, train=True)
+                    dist.all_reduce(gv2, op=dist.ReduceOp.SUM)
+                    eng2.apply()
+
+            for i in range(50):
+                alt_step(i)
+            barrier()
+            t0 = time.perf_counter()
+            for i in range(a.alt_steps):
+                alt_step(i)
+            barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            alt = {"global_batch": a.alt_batch, "value": a.alt_steps * a.alt_batch / el, "unit": "frames/s",
+                   "ms_per_step": el / a.alt_steps * 1e3, "steps": a.alt_steps,
+                   "note": "training steps only, same matrix / model / split; launch-latency bound at this size"}
+            eng2.close()
+    if rank == 0:
+        if alt is not None:
+            out["secondary"] = alt
         if not a.no_cpu_baseline and world == 1:
             cpu_batch = min(a.batch, 65536)   # bounded sample: frames/s of the CPU GEMMs does not depend on the batch size
             sample_rows = min(n_local, 4 * cpu_batch + lag)
@@ -249,7 +299,6 @@ def main():
                           f"{sample_rows} frames, {dt:.1f} s",
             }
         print(json.dumps(out))
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

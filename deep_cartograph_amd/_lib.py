@@ -76,6 +76,8 @@ SIGNATURES = {
     "dcv_mlp_profile_begin": (C.c_int, [_P, _I32, _I32]),
     "dcv_mlp_profile_end": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_infer": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
+    "dcv_mlp_input_sensitivity_workspace": (_SZ, [_P, _I64]),
+    "dcv_mlp_input_sensitivity": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "dcv_kmeans_workspace": (_SZ, [_I64, _I32, _I32]),
     "dcv_kmeans_step": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P]),
     "dcv_nearest_rows_workspace": (_SZ, [_I64, _I32, _I32]),

@@ -207,6 +207,31 @@ __global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict
     }
 }
 
+// dZ_last[r][c] = g[c] * act'(H_last[r][c]): the gradient of s = sum_j cv_j w.r.t. the network output is the
+// same vector for every frame (the layers after the network are affine)
+__global__ __launch_bounds__(256) void seed_grad_kernel(const float* __restrict__ H, int64_t ldh, int64_t rows, int d, int act,
+                                                        const float* __restrict__ g, float* __restrict__ dZ, int64_t ld_dz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * d) return;
+    const int64_t r = i / d;
+    const int c = (int)(i - r * d);
+    dZ[r * ld_dz + c] = g[c] * act_grad_from_out(act, H[r * ldh + c]);
+}
+
+// part[block][c] = sum over the block's rows of |G[r][c]| * scale[c] (float64, rows in index order)
+constexpr int kAbsRows = 256;
+__global__ __launch_bounds__(256) void abs_colsum_kernel(const float* __restrict__ G, int64_t ldg, int64_t rows, int F,
+                                                         const float* __restrict__ scale, double* __restrict__ part) {
+    const int64_t r0 = (int64_t)blockIdx.x * kAbsRows;
+    const int64_t r1 = r0 + kAbsRows < rows ? r0 + kAbsRows : rows;
+    for (int c = threadIdx.x; c < F; c += 256) {
+        double acc = 0.0;
+        const double sc = (double)scale[c];
+        for (int64_t r = r0; r < r1; ++r) acc += fabs((double)G[r * ldg + c]) * sc;
+        part[(int64_t)blockIdx.x * F + c] = acc;
+    }
+}
+
 // out[i] = sum_b part[b][i], one wave per output, fixed combination tree
 __global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restrict__ part, int nblocks, int width,
                                                           double* __restrict__ out) {
@@ -958,4 +983,64 @@ extern "C" int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t l
     // y = (h - tmean) @ tevecs ; out = (y - pmean) / prange   -- the linear projection kernel
     return dcv_project_linear(last.H, n, d, last.ldh, tmean_d ? tmean_d : m->zeros_d, m->ones_d, tevecs_d ? tevecs_d : m->ident, d,
                               nullptr, pmean_d, prange_d, out_d, minmax_d, m->proj_ws, m->proj_ws_bytes, stream);
+}
+
+// Input-gradient pass of the sensitivity analysis (reference cv_calculator.py:1893-1921 ->
+// mlcolvar.explain.sensitivity_analysis, metric "mean_abs_val"): for the rows given,
+// sens[i] = sum_r | d(sum_j cv_j)/d xn[r][i] | * scale[i], where the layers behind the network (TICA,
+// post-normalisation) enter through the constant vector g = d(sum_j cv_j)/d(network output).
+extern "C" size_t dcv_mlp_input_sensitivity_workspace(const dcv_mlp* m, int64_t n) {
+    if (!m || n < 1) return 0;
+    const size_t F = (size_t)m->desc.dims[0];
+    return align_up((size_t)n * F * sizeof(float), 256) + (size_t)cdiv(n, kAbsRows) * F * sizeof(double);
+}
+
+extern "C" int dcv_mlp_input_sensitivity(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld, const float* gout_d,
+                                         const float* scale_d, double* sens_d, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
+    DCV_REQUIRE(m && Xn_d && gout_d && scale_d && sens_d && workspace, "dcv_mlp_input_sensitivity: null argument");
+    DCV_REQUIRE(n >= 1 && n <= m->rows_cap, "dcv_mlp_input_sensitivity: n=%lld outside [1, %lld] (chunk the call)", (long long)n,
+                (long long)m->rows_cap);
+    DCV_REQUIRE(workspace_bytes >= dcv_mlp_input_sensitivity_workspace(m, n), "dcv_mlp_input_sensitivity: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int F = m->desc.dims[0];
+    DCV_REQUIRE(ld >= F, "dcv_mlp_input_sensitivity: ld=%lld < F=%d", (long long)ld, F);
+    const int n_run = m->desc.model == DCV_MODEL_AE ? m->desc.latent_layer : m->L;
+    int rc = run_forward(m, Xn_d, ld, identity_rows(), n, n_run, s);
+    if (rc) return rc;
+    const LayerPlan& last = m->layers[n_run - 1];
+    float* dz_cur = m->dZ[0];
+    float* dz_nxt = m->dZ[1];
+    hipLaunchKernelGGL(seed_grad_kernel, dim3((unsigned)cdiv(n * last.out, 256)), dim3(256), 0, s, last.H, last.ldh, n, last.out, last.act,
+                       gout_d, dz_cur, m->ld_dz);
+    DCV_CHECK_LAUNCH();
+    for (int l = n_run - 1; l >= 1; --l) {   // dZ_{l-1} = (dZ_l W_l) * act'(H_{l-1})
+        LayerPlan& p = m->layers[l];
+        LayerPlan& q = m->layers[l - 1];
+        Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
+        Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
+        EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
+        int bblocks = 0;
+        rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, n, p.in, p.out, 0, eg, s, &bblocks);
+        if (rc) return rc;
+        float* tmp = dz_cur;
+        dz_cur = dz_nxt;
+        dz_nxt = tmp;
+    }
+    float* G = static_cast<float*>(workspace);
+    double* part = reinterpret_cast<double*>(static_cast<char*>(workspace) + align_up((size_t)n * F * sizeof(float), 256));
+    {   // dXn = dZ_0 W_0
+        const LayerPlan& p = m->layers[0];
+        Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
+        Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
+        EpiStore es{G, F, quad_ok(G, F)};
+        rc = launch_gemm<kNN, EpiStore>(Ad, Bd, n, p.in, p.out, 0, es, s);
+        if (rc) return rc;
+    }
+    const int nb = (int)cdiv(n, kAbsRows);
+    hipLaunchKernelGGL(abs_colsum_kernel, dim3(nb), dim3(256), 0, s, G, (int64_t)F, n, F, scale_d, part);
+    DCV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(F), dim3(64), 0, s, part, nb, F, sens_d);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
 }

@@ -221,7 +221,7 @@ class CVCalculator(ABC):
             projection = self.project_data(self.training_data, normalize_data=False)
             if self.comm.rank == 0:
                 self.save_model()
-                self.sensitivity_analysis()
+            self.sensitivity_analysis()   # every rank computes (collectives inside), rank 0 writes
             self.comm.barrier()
             projection_df = pd.DataFrame(projection.numpy(), columns=self.cv_labels)
         return projection_df
@@ -401,6 +401,8 @@ class LinearCalculator(CVCalculator):
     def sensitivity_analysis(self):
         """|W| per feature, ascending, one CSV per CV dimension (reference :993-1047, without
         the plots and the per-atom mapping, which need matplotlib / MDAnalysis)."""
+        if self.comm.rank != 0:
+            return
         sens = np.abs(self.cv)
         for i in range(sens.shape[1]):
             out = Path(self.sensitivity_output_folder) / f"sensitivity_analysis_{i + 1}"
@@ -836,6 +838,52 @@ class NonLinear(CVCalculator):
                 Xn = X
         out, _ = self._infer(Xn, with_post=True)
         return out.cpu()
+
+    # ---- sensitivity
+    def summed_cv_gradient(self) -> np.ndarray:
+        """d(sum_j cv_j)/d(network output): the layers behind the network are affine, so this is one
+        vector for every frame.  y = (h - tmean) @ evecs (Deep-TICA), cv = (y - pmean) / prange."""
+        st = self.cv
+        d_lat = st["dims"][st["latent"]]
+        inv_range = np.ones(self.cv_dimension if st.get("tica") is not None else d_lat, dtype=np.float64)
+        if st.get("post") is not None:
+            inv_range = 1.0 / np.asarray(st["post"][1], dtype=np.float64)
+        if st.get("tica") is not None:
+            return np.asarray(st["tica"][1], dtype=np.float64) @ inv_range
+        return inv_range
+
+    def sensitivity_scores(self) -> np.ndarray:
+        """mlcolvar.explain.sensitivity_analysis(model, dataset, metric='mean_abs_val') restated
+        (reference call site :1903): s_i = mean_r |d(sum_j cv_j)/dx_i(x_r)| * std_i over the samples
+        of dataset['data'] (x_t rows for Deep-TICA), normalised to sum to one.  The model takes raw
+        features (norm_in is its first layer), so d/dx_i = d/dxn_i / norm_range_i.  One input-gradient
+        pass of the HIP engine over the resident normalised matrix."""
+        rows = self.n_samples_local()
+        dev = self.training_normalized.device
+        raw = hip.col_stats_raw(self.training_data[:rows] if self.training_data.is_cuda else self.training_data[:rows].to(dev))
+        n_glob = int(self.comm.sum_scalar(float(rows), device=dev))
+        std = hip.finalize_stats(reduce_col_stats(raw, self.comm), n_glob)["std"].astype(np.float64)
+        scale = std.copy()
+        if self.cv.get("norm_in") is not None:
+            scale = scale / np.asarray(self.cv["norm_in"][1], dtype=np.float64)
+        g = self.summed_cv_gradient()
+        acc = self.engine.input_sensitivity(self.training_normalized[:rows], _dev(g.astype(np.float32), dev), _dev(scale.astype(np.float32), dev))
+        acc = self.comm.sum_(acc).cpu().numpy() if self.comm.active else acc.cpu().numpy()
+        score = acc / float(n_glob)
+        return score / score.sum()
+
+    def sensitivity_analysis(self):
+        """sensitivity_analysis.csv as NonLinear.sensitivity_analysis writes it (reference :1893-1921):
+        features ascending by sensitivity.  Plots and the per-atom mapping need matplotlib / MDAnalysis."""
+        if self.cv is None or self.engine is None or self.training_normalized is None:
+            return
+        score = self.sensitivity_scores()
+        if self.comm.rank != 0:
+            return
+        order = np.argsort(score)
+        Path(self.sensitivity_output_folder).mkdir(parents=True, exist_ok=True)
+        pd.DataFrame({"sensitivity": score[order]}, index=list(np.array(self.features_ref_labels)[order])).to_csv(
+            os.path.join(self.sensitivity_output_folder, "sensitivity_analysis.csv"))
 
     # ---- persistence
     def to_torch_module(self) -> torch.nn.Module:

@@ -365,6 +365,27 @@ class Mlp:
         return {(c // 3, kinds[c % 3]): (float(ms[c]), int(cnt[c])) for c in range(3 * self.L) if cnt[c] > 0}
 
     # -- inference
+    def input_sensitivity(self, Xn, gout, scale):
+        """sum over the rows of Xn of |d(sum_j cv_j)/d xn_i| * scale_i  (float64 [F], device),
+        chunked to the engine's row capacity.  gout [d_latent]: gradient of the summed CV with
+        respect to the network output; scale [F]."""
+        _require_gpu(Xn, gout, scale)
+        _check_matrix(Xn)
+        n, F = Xn.shape
+        total = torch.zeros(F, dtype=torch.float64, device=Xn.device)
+        part = torch.empty(F, dtype=torch.float64, device=Xn.device)
+        cap = min(self.rows_cap, max(1, n))
+        nbytes = self.lib.dcv_mlp_input_sensitivity_workspace(self.h, cap)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=Xn.device)
+        gout = gout.to(torch.float32).contiguous()
+        scale = scale.to(torch.float32).contiguous()
+        for s in range(0, n, cap):
+            e = min(n, s + cap)
+            check(self.lib.dcv_mlp_input_sensitivity(self.h, _ptr(Xn[s:e]), e - s, Xn.stride(0), _ptr(gout), _ptr(scale), _ptr(part),
+                                                     _ptr(ws), ws.numel(), _stream()), "dcv_mlp_input_sensitivity")
+            total += part
+        return total
+
     def infer(self, Xn, *, tmean=None, tevecs=None, pmean=None, prange=None, want_out=True, want_minmax=False):
         """Forward of every row of Xn (chunked to the engine's row capacity).
         Returns (out [n, d] or None, minmax [2, d] or None)."""

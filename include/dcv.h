@@ -207,6 +207,18 @@ int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld,
                   const float* tmean_d, const float* tevecs_d, const float* pmean_d,
                   const float* prange_d, float* out_d, float* minmax_d, void* stream);
 
+/* Input-gradient pass of the neural sensitivity analysis.  Replaces
+ * mlcolvar.explain.sensitivity_analysis(metric="mean_abs_val") as called by
+ * NonLinear.sensitivity_analysis, cv_calculator.py:1893-1921: for the n rows given (n <= the
+ * engine's row capacity; chunk larger matrices and add the results)
+ *   sens[i] = sum_r | d(sum_j cv_j)/d xn[r][i] | * scale[i]          (float64, F values, overwritten)
+ * gout_d (d_latent floats) is the constant gradient of sum_j cv_j with respect to the output of
+ * the network layers (the TICA projection and the post-normalisation behind them are affine);
+ * scale_d (F floats) is the per-feature factor (dataset std / norm_in range). */
+size_t dcv_mlp_input_sensitivity_workspace(const dcv_mlp* m, int64_t n);
+int dcv_mlp_input_sensitivity(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld, const float* gout_d,
+                              const float* scale_d, double* sens_d, void* ws_d, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- k-means (a17-a19)
  * Replaces the Lloyd iterations of sklearn.cluster.KMeans as driven by
  * statistics.kmeans_clustering, statistics.py:159-197 (algorithm: SURVEY.md Appendix A.8).

@@ -179,6 +179,9 @@ def test_deep_tica_calculator_vs_oracle(features, tmp_path):
     np.testing.assert_allclose(loaded.project_data(torch.from_numpy(X.copy())).numpy(), df.to_numpy(), atol=5e-5)
     assert (tmp_path / "deep_tica" / "training" / "training_metrics.zip").exists()
     assert (tmp_path / "deep_tica" / "training" / "eigenvalues.txt").exists()
+    # sensitivity analysis (f3): input-gradient pass of the HIP engine vs autograd through the exported model on
+    # dataset['data'] = the x_t rows (lag 1); tolerance 1e-3 relative (leaky-ReLU kinks, fp32 products)
+    _check_sensitivity(tmp_path / "deep_tica", ts, X[:-1], names)
 
 
 def test_ae_calculator_vs_oracle(features, tmp_path):
@@ -202,6 +205,17 @@ def test_ae_calculator_vs_oracle(features, tmp_path):
     assert {n.split(".")[0] for n, _ in ts.named_parameters()} == {"encoder", "decoder"}
     with torch.no_grad():
         np.testing.assert_allclose(ts(torch.from_numpy(X)).numpy(), df.to_numpy(), atol=5e-5)
+    _check_sensitivity(tmp_path / "ae", ts, X, names)
+
+
+def _check_sensitivity(folder, ts_model, X_rows, names):
+    sens = pd.read_csv(folder / "sensitivity_analysis" / "sensitivity_analysis.csv", index_col=0)
+    exp = onn.sensitivity_mean_abs(ts_model, torch.from_numpy(np.ascontiguousarray(X_rows)))
+    got = sens["sensitivity"].to_numpy()
+    assert list(sens.columns) == ["sensitivity"] and len(got) == len(names)
+    assert np.all(np.diff(got) >= 0) and abs(got.sum() - 1.0) < 1e-9       # ascending, normalised to one
+    by_name = {n: v for n, v in zip(sens.index, got)}
+    np.testing.assert_allclose([by_name[n] for n in names], exp, rtol=1e-3, atol=1e-7)
 
 
 def test_reference_torchscript_zip_loads(features, golden_nn, golden_proj, tmp_path):

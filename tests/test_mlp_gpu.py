@@ -273,3 +273,33 @@ def test_infer_reproduces_reference_torchscript(features, golden_nn, golden_proj
     np.testing.assert_allclose(out.cpu().numpy(), g["deep_tica.output"], atol=2e-5)
     assert np.mean(ol.csv_round4(out.cpu().numpy()) == golden_proj["deep_tica"]) > 0.97
     eng.close()
+
+
+@pytest.mark.parametrize("dims,acts,n,cap", [
+    ([70, 33, 17, 3], ["tanh", "leaky_relu", None], 1000, 384),       # ragged widths, chunked (3 calls)
+    ([512, 256, 128, 4], ["leaky_relu", "leaky_relu", None], 5000, 8192),
+    ([54, 5], [None], 164, 164),                                      # a single Linear
+])
+def test_input_sensitivity_matches_autograd(dims, acts, n, cap):
+    """dcv_mlp_input_sensitivity: sum_r |d(g . net(xn_r))/d xn_i| * scale_i against float64
+    autograd through the same Linear chain; tolerance 2e-4 relative (fp32 products vs float64)."""
+    from deep_cartograph_amd import hip
+
+    rng = np.random.default_rng(5)
+    Xn = rng.standard_normal((n, dims[0])).astype(np.float32)
+    torch.manual_seed(9)
+    seq = onn.feed_forward(dims, acts)
+    lins = linears_of(seq)
+    g = rng.standard_normal(dims[-1]).astype(np.float32)
+    scale = rng.uniform(0.5, 2.0, dims[0]).astype(np.float32)
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=cap, lag=0, tica_reg=1e-6)
+    push_params(eng, lins)
+    got = eng.input_sensitivity(torch.from_numpy(Xn).cuda(), torch.from_numpy(g).cuda(), torch.from_numpy(scale).cuda()).cpu().numpy()
+    ref = seq.double()
+    x = torch.from_numpy(Xn).double().requires_grad_(True)
+    out = (ref(x) * torch.from_numpy(g).double()).sum()
+    grad = torch.autograd.grad(out, x)[0].numpy()
+    exp = (np.abs(grad) * scale.astype(np.float64)).sum(axis=0)
+    assert got.shape == exp.shape
+    np.testing.assert_allclose(got, exp, rtol=2e-4)
+    eng.close()

@@ -49,6 +49,18 @@ class Comm:
         self._dist.all_gather(out, t.contiguous(), group=self.group)
         return out
 
+    def all_gather_rows(self, t: torch.Tensor) -> torch.Tensor:
+        """Concatenation in rank order of per-rank tensors whose first dimension differs (the
+        frame shards): sizes are exchanged first, shards padded to the largest for the collective."""
+        if not self.active:
+            return t
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        sizes = [int(x.item()) for x in self.all_gather(n)]
+        pad = torch.zeros((max(sizes),) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        pad[: t.shape[0]] = t
+        parts = self.all_gather(pad)
+        return torch.cat([p[:m] for p, m in zip(parts, sizes)], dim=0)
+
     def sum_scalar(self, v: float, device="cpu") -> float:
         t = torch.tensor([float(v)], dtype=torch.float64, device=device)
         return float(self.sum_(t).item())
@@ -104,3 +116,18 @@ def reduce_nearest(dist: torch.Tensor, rows: torch.Tensor, comm: Comm):
     best_d = d_all.min(dim=0).values
     cand = torch.where(d_all == best_d[None, :], r_all, torch.full_like(r_all, torch.iinfo(torch.int64).max))
     return best_d, cand.min(dim=0).values
+
+
+def global_topk(values: torch.Tensor, payload: torch.Tensor, m: int, comm: Comm) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The m largest `values` over every rank's shard, largest first (ties: lower rank, then lower
+    local index -- the order a single process sees in the concatenated array with a stable sort).
+    Returns (values [m], owner rank [m], payload rows [m, ...]); every rank gets the same result."""
+    m_loc = min(m, values.shape[0])
+    order = torch.argsort(values, descending=True, stable=True)[:m_loc]
+    v_loc, p_loc = values[order], payload[order]
+    if not comm.active:
+        return v_loc, torch.zeros(m_loc, dtype=torch.int64, device=values.device), p_loc
+    r_loc = torch.full((m_loc,), comm.rank, dtype=torch.int64, device=values.device)
+    v_all, r_all, p_all = comm.all_gather_rows(v_loc), comm.all_gather_rows(r_loc), comm.all_gather_rows(p_loc)
+    pick = torch.argsort(v_all, descending=True, stable=True)[:m]   # rank-major concatenation: stable = rank, then index
+    return v_all[pick], r_all[pick], p_all[pick]

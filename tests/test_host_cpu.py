@@ -198,6 +198,16 @@ def _worker(rank, world, port, tmpdir):
     rows_l = torch.from_numpy(d.argmin(0) + b)
     _, rows = parallel.reduce_nearest(dist_l, rows_l, comm)
     ok &= np.array_equal(rows.numpy(), np.linalg.norm(X.astype(np.float64)[:, None, :] - C[None], axis=2).argmin(0))
+    # ragged gather in rank (= frame) order, as the distributed k-means++ seeding uses it
+    ok &= np.array_equal(comm.all_gather_rows(Xl).numpy(), X)
+    # farthest-point candidates of the empty-cluster relocation: global top-m with payload rows, ties by rank then index
+    vals = np.round(np.abs(X64[:, 0]), 1)                     # rounded: ties on purpose
+    top = torch.topk(torch.from_numpy(vals), 5)
+    gv, gr, gp = parallel.global_topk(top.values, Xl[top.indices].double(), 5, comm)
+    all_vals = np.round(np.abs(X.astype(np.float64)[:, 0]), 1)
+    ok &= np.array_equal(np.sort(gv.numpy())[::-1], np.sort(all_vals)[::-1][:5]) and bool(np.all(np.diff(gv.numpy()) <= 0))
+    ok &= bool(np.all(np.round(np.abs(gp.numpy()[:, 0]), 1) == gv.numpy()))                # payload rows travel with their values
+    ok &= bool(np.all((gr.numpy() >= 0) & (gr.numpy() < world)))
     with open(os.path.join(tmpdir, f"ok_{rank}"), "w") as f:
         f.write("1" if ok else "0")
     dist.destroy_process_group()

@@ -303,3 +303,85 @@ def test_input_sensitivity_matches_autograd(dims, acts, n, cap):
     assert got.shape == exp.shape
     np.testing.assert_allclose(got, exp, rtol=2e-4)
     eng.close()
+
+
+# ----------------------------------------------------------------------------- two ranks on one GPU (gloo)
+def _dp_rank(rank, world, port, tmpdir):
+    """One data-parallel rank of the bench's collective path: forward, all-reduce of the batch statistics, backward,
+    all-reduce of the gradient buffer, Adam -- on this rank's contiguous block of frames."""
+    import os
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from deep_cartograph_amd import hip
+
+    torch.cuda.set_device(0)
+    z = np.load(os.path.join(tmpdir, "dp.npz"))
+    Xn, dims, lag, lb, steps = z["Xn"], [int(v) for v in z["dims"]], int(z["lag"]), int(z["lb"]), int(z["steps"])
+    n_local = Xn.shape[0] // world
+    Xd = torch.from_numpy(Xn[rank * n_local:(rank + 1) * n_local]).cuda()
+    acts = ["leaky_relu"] * (len(dims) - 2) + [None]
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=lb, lag=lag, tica_reg=1e-6, lr=1e-3)
+    eng.set_linears([(z[f"w{i}"], z[f"b{i}"]) for i in range(len(dims) - 1)])
+    eng.reset_log(4 * steps + 8)
+    sv, gv = eng.stats_view(), eng.grads_view()
+    for i in range(steps):
+        r0 = i * lb
+        eng.forward(Xd, row0=r0, batch=lb)
+        dist.all_reduce(sv, op=dist.ReduceOp.SUM)
+        eng.backward(Xd, row0=r0, batch=lb, global_batch=lb * world, train=True)
+        dist.all_reduce(gv, op=dist.ReduceOp.SUM)
+        eng.apply()
+    torch.cuda.synchronize()
+    lin = eng.get_linears()
+    np.savez(os.path.join(tmpdir, f"dp_rank{rank}.npz"), loss=eng.read_log()[:steps, 0], **{f"w{i}": w for i, (w, _) in enumerate(lin)})
+    eng.close()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_match_single_process(tmp_path):
+    """SURVEY 8e, Deep-TICA step: two ranks (frame blocks, batch statistics and gradients all-reduced) follow the same
+    trajectory as one process given the union batch through a gather index; tolerance 2e-5 on the weights after 4 steps
+    (summation order of the fp32 partial sums differs), losses 1e-5."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from deep_cartograph_amd import hip
+
+    dims, lag, lb, steps, world = [64, 32, 16, 3], 5, 640, 4, 2
+    X = ar_features(2 * 3000, dims[0], 21)
+    Xn, _, _ = normalized(X)
+    torch.manual_seed(4)
+    acts = ["leaky_relu"] * (len(dims) - 2) + [None]
+    seq = onn.feed_forward(dims, acts)
+    lins = linears_of(seq)
+    save = {f"w{i}": l.weight.detach().numpy() for i, l in enumerate(lins)}
+    save.update({f"b{i}": l.bias.detach().numpy() for i, l in enumerate(lins)})
+    np.savez(tmp_path / "dp.npz", Xn=Xn, dims=np.array(dims), lag=lag, lb=lb, steps=steps, **save)
+    # single process: the same pairs per step (rank-major) through a gather index
+    n_local = Xn.shape[0] // world
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=lb * world, lag=lag, tica_reg=1e-6, lr=1e-3)
+    push_params(eng, lins)
+    eng.reset_log(4 * steps + 8)
+    Xd = torch.from_numpy(Xn).cuda()
+    for i in range(steps):
+        idx = torch.cat([torch.arange(r * n_local + i * lb, r * n_local + (i + 1) * lb) for r in range(world)]).cuda()
+        eng.train_step(Xd, idx=idx)
+    torch.cuda.synchronize()
+    ref_lin = eng.get_linears()
+    ref_loss = eng.read_log()[:steps, 0]
+    eng.close()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_rank, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        z = np.load(tmp_path / f"dp_rank{r}.npz")
+        np.testing.assert_allclose(z["loss"], ref_loss, rtol=1e-5, atol=1e-6)
+        for i, (w, _) in enumerate(ref_lin):
+            np.testing.assert_allclose(z[f"w{i}"], w, atol=2e-5)

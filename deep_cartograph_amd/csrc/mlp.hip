@@ -455,6 +455,149 @@ __global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------ fused backward of a narrow last layer
+// Deep-TICA's last Linear maps K hidden units to D <= 8 outputs: as separate products its wgrad, dgrad and the
+// two bias-gradient passes each stream the K-wide activations H (or write the K-wide dZ) for a handful of
+// flops per byte.  One pass does all of it: per row r
+//   g      = dL/dz_last[r]  (D values; the tica_dF formula above, evaluated in place)
+//   dW    += g (x) H[r]          -> slab[block][D][K]          (wgrad partial of the last layer)
+//   db    += g                   -> bpart_last[block][D]
+//   dZ[r]  = (g W) * act'(H[r])  -> written once, 16-byte stores (dgrad of the last layer)
+//   db'   += dZ[r]               -> bpart_prev[block][K]       (bias gradient of the layer before)
+// HBM: K floats read + K floats written per row.  Thread (row group rl, 4 columns c4): D x 4 weights and
+// D x 4 + 4 accumulators in registers; the 256 / (K/4) row groups of a block are combined through LDS in
+// fixed order, blocks by reduce_grads_kernel in float64.
+template <int D>
+__global__ __launch_bounds__(256) void head_backward_kernel(const float* __restrict__ F, int64_t ldf, int B, int lag_off,
+                                                            const float* __restrict__ gradp, int act_last,
+                                                            const float* __restrict__ H, int64_t ldh, int K, int act_prev,
+                                                            const float* __restrict__ W, int64_t rows_per_block,
+                                                            float* __restrict__ dZ, int64_t ldz, float* __restrict__ slab,
+                                                            float* __restrict__ bpart_last, float* __restrict__ bpart_prev) {
+    constexpr int U = 4;                        // rows in flight per thread
+    extern __shared__ float s_mem[];
+    float* s_g = s_mem;                         // mu | Gu | Gv | c
+    float* s_gf = s_mem + (2 * D + 2 * D * D);  // [groups][U][D] loss gradients of the rows in flight
+    const int t = threadIdx.x;
+    const int C4 = K / 4, groups = 256 / C4;    // a row group (C4 <= 64 lanes) lies inside one wave
+    float* s_red = s_gf + groups * U * D;       // [groups][(D + 1) * K + D]
+    for (int i = t; i < 2 * D + 2 * D * D; i += 256) s_g[i] = gradp[i];
+    __syncthreads();
+    const float* mu = s_g;
+    const float* Gu = s_g + D;
+    const float* Gv = Gu + D * D;
+    const float* cv = Gv + D * D;
+    const int c4 = t % C4, rl = t / C4;
+    const int64_t rows = (int64_t)B + lag_off;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    float4 w[D], aw[D];
+    float4 ab = make_float4(0.f, 0.f, 0.f, 0.f);
+    float al[D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        w[j] = *reinterpret_cast<const float4*>(W + (int64_t)j * K + c4 * 4);
+        aw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        al[j] = 0.f;
+    }
+    float* gmine = s_gf + rl * U * D;
+    for (int64_t rb = r0 + rl; rb < r1; rb += (int64_t)groups * U) {
+        float4 h[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {   // the K-wide loads first: U rows in flight
+            const int64_t r = rb + (int64_t)q * groups;
+            h[q] = r < r1 ? *reinterpret_cast<const float4*>(H + r * ldh + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        // dL/dz_last of the U rows: component i by lane i, i + C4, ... of the row group, shared through LDS
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t r = rb + (int64_t)q * groups;
+            for (int i = c4; i < D; i += C4) {
+                float gi = 0.f;
+                if (r < r1) {
+                    const bool has_t = r < B, has_l = r >= lag_off;
+                    const float* fr = F + r * ldf;
+                    if (has_t) {
+                        gi = cv[i];
+                        const float* fv = F + (r + lag_off) * ldf;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            gi = fmaf(Gu[i * D + k], fr[k] - mu[k], gi);
+                            gi = fmaf(Gv[i * D + k], fv[k] - mu[k], gi);
+                        }
+                    }
+                    if (has_l) {
+                        const float* fw = F + (r - lag_off) * ldf;
+                        float gl = 0.f;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) gl = fmaf(Gv[i * D + k], fw[k] - mu[k], gl);
+                        gi += gl;
+                    }
+                    gi *= act_grad_from_out(act_last, fr[i]);
+                }
+                gmine[q * D + i] = gi;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+            const int64_t r = rb + (int64_t)q * groups;
+            if (r >= r1) break;
+            float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                const float g = gmine[q * D + j];
+                z.x = fmaf(g, w[j].x, z.x); z.y = fmaf(g, w[j].y, z.y); z.z = fmaf(g, w[j].z, z.z); z.w = fmaf(g, w[j].w, z.w);
+                aw[j].x = fmaf(g, h[q].x, aw[j].x); aw[j].y = fmaf(g, h[q].y, aw[j].y);
+                aw[j].z = fmaf(g, h[q].z, aw[j].z); aw[j].w = fmaf(g, h[q].w, aw[j].w);
+                if (c4 == 0) al[j] += g;
+            }
+            z.x *= act_grad_from_out(act_prev, h[q].x); z.y *= act_grad_from_out(act_prev, h[q].y);
+            z.z *= act_grad_from_out(act_prev, h[q].z); z.w *= act_grad_from_out(act_prev, h[q].w);
+            *reinterpret_cast<float4*>(dZ + r * ldz + c4 * 4) = z;
+            ab.x += z.x; ab.y += z.y; ab.z += z.z; ab.w += z.w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // gmine is rewritten by the next iteration
+    }
+    // combine the row groups: s_red[rl] = [dW (D x K) | db' (K) | db (D)]
+    const int stride = (D + 1) * K + D;
+    float* mine = s_red + (int64_t)rl * stride;
+#pragma unroll
+    for (int j = 0; j < D; ++j) *reinterpret_cast<float4*>(mine + j * K + c4 * 4) = aw[j];
+    *reinterpret_cast<float4*>(mine + D * K + c4 * 4) = ab;
+    if (c4 == 0) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) mine[(D + 1) * K + j] = al[j];
+    }
+    __syncthreads();
+    for (int i = t; i < stride; i += 256) {
+        float tot = 0.f;
+        for (int q = 0; q < groups; ++q) tot += s_red[(int64_t)q * stride + i];
+        if (i < D * K) slab[(int64_t)blockIdx.x * D * K + i] = tot;
+        else if (i < (D + 1) * K) bpart_prev[(int64_t)blockIdx.x * K + (i - D * K)] = tot;
+        else bpart_last[(int64_t)blockIdx.x * D + (i - (D + 1) * K)] = tot;
+    }
+}
+
+typedef void (*head_backward_fn_t)(const float*, int64_t, int, int, const float*, int, const float*, int64_t, int, int, const float*, int64_t,
+                                   float*, int64_t, float*, float*, float*);
+static head_backward_fn_t head_backward_fn(int d) {
+    switch (d) {
+        case 1: return head_backward_kernel<1>;
+        case 2: return head_backward_kernel<2>;
+        case 3: return head_backward_kernel<3>;
+        case 4: return head_backward_kernel<4>;
+        case 5: return head_backward_kernel<5>;
+        case 6: return head_backward_kernel<6>;
+        case 7: return head_backward_kernel<7>;
+        case 8: return head_backward_kernel<8>;
+        default: return nullptr;
+    }
+}
+
 // ------------------------------------------------------------------ autoencoder loss
 // SSE = sum ((y - xn) * range)^2 over rows x F ; part[block]
 __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Xn,
@@ -552,6 +695,34 @@ static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t*
     *splits = cdiv(rows, kc);
 }
 
+// the fused backward of the last layer applies to a Deep-TICA network whose last Linear is narrow (<= 8 outputs)
+// and whose input width tiles a 256-thread block in 16-byte segments
+static size_t head_lds_bytes(int D, int K) {
+    const int groups = 256 / (K / 4);
+    return ((size_t)(2 * D + 2 * D * D) + (size_t)groups * 4 * D + (size_t)groups * ((size_t)(D + 1) * K + D)) * sizeof(float);
+}
+static bool head_fusable(const dcv_mlp* m) {
+    static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
+    if (off || m->L < 2) return false;
+    const LayerPlan& p = m->layers[m->L - 1];
+    const LayerPlan& q = m->layers[m->L - 2];
+    const int K = p.in;
+    if (p.out > 8 || K % 4 != 0 || K / 4 > 256 || 256 % (K / 4) != 0) return false;
+    if (!quad_ok(q.H, q.ldh) || !quad_ok(m->dZ[0], m->ld_dz) || !quad_ok(m->dZ[1], m->ld_dz) || !quad_ok(m->params + p.w_off, K)) return false;
+    if (K / 4 > 64) return false;   // a row group must lie inside one wave
+    return head_lds_bytes(p.out, K) <= 60 * 1024;
+}
+// blocks of the fused pass: about four per CU, at least 32 rows each, bounded by the partial buffers
+static void head_plan(const dcv_mlp* m, int64_t R, int64_t* rows_per_block, int64_t* blocks) {
+    const LayerPlan& p = m->layers[m->L - 1];
+    int64_t want = 4 * (int64_t)num_cus();
+    if (want > p.max_splits) want = p.max_splits;
+    int64_t rpb = cdiv(cdiv(R, want), 32) * 32;
+    if (rpb < 32) rpb = 32;
+    *rows_per_block = rpb;
+    *blocks = cdiv(R, rpb);
+}
+
 static void mlp_free(dcv_mlp* m) {
     if (!m) return;
     auto f = [](void* p) { if (p) (void)hipFree(p); };
@@ -624,6 +795,11 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         // a smaller batch may use smaller chunks; bound the splits by the 256-row floor
         p.max_splits = cdiv(m->rows_cap, 256) > p.max_splits ? p.max_splits : cdiv(m->rows_cap, 256);
         if (p.max_splits < 1) p.max_splits = 1;
+        if (l == L - 1 && p.out <= 8) {   // the fused backward of a narrow last layer writes one partial per block (head_plan)
+            int64_t hb = 4 * (int64_t)num_cus();
+            if (hb > cdiv(m->rows_cap, 32)) hb = cdiv(m->rows_cap, 32);
+            if (hb > p.max_splits) p.max_splits = hb;
+        }
         rc = dmalloc(&p.H, (size_t)m->rows_cap * p.ldh);
         if (rc == DCV_OK) rc = dmalloc(&p.slab, (size_t)p.max_splits * p.in * p.out);
         if (rc == DCV_OK) rc = dmalloc(&p.bpart, (size_t)cdiv(m->rows_cap, 32) * p.out);  // row tiles of the dgrad epilogue can be as short as 32
@@ -824,14 +1000,18 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     const LayerPlan& last = m->layers[L - 1];
     float* dz_cur = m->dZ[0];
     float* dz_nxt = m->dZ[1];
+    bool fused_head = false;
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
         hipLaunchKernelGGL(tica_grad_fn(m->d_out), dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
                            train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
         DCV_CHECK_LAUNCH();
         if (!train) return DCV_OK;
-        hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
-                           lag_offset(m, idx_d, batch), m->gradp, last.act, dz_cur, m->ld_dz);
-        DCV_CHECK_LAUNCH();
+        fused_head = head_fusable(m);
+        if (!fused_head) {
+            hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
+                               lag_offset(m, idx_d, batch), m->gradp, last.act, dz_cur, m->ld_dz);
+            DCV_CHECK_LAUNCH();
+        }
     } else {
         const int F = m->desc.dims[0];
         hipLaunchKernelGGL(ae_log_kernel, dim3(1), dim3(64), 0, s, m->stats, (double)global_batch, F, m->log, m->log_count, m->log_cap, m->log_width);
@@ -850,8 +1030,10 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     // bias-gradient partials of the last layer come from a column-sum pass over dZ_last; those of
     // every other layer fall out of the dgrad epilogue that produces its dZ
     int bblocks = (int)cdiv(R, kColsumRows);
-    hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, last.out, m->ld_dz, m->layers[L - 1].bpart);
-    DCV_CHECK_LAUNCH();
+    if (!fused_head) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, last.out, m->ld_dz, m->layers[L - 1].bpart);
+        DCV_CHECK_LAUNCH();
+    }
     for (int l = L - 1; l >= 0; --l) {
         LayerPlan& p = m->layers[l];
         // wgrad: dW = dZ^T In  (M = out, N = in, K = rows)
@@ -861,6 +1043,34 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
             splits = p.max_splits;
             kc = cdiv(cdiv(R, splits), 32) * 32;
             splits = cdiv(R, kc);
+        }
+        if (fused_head && l == L - 1) {
+            // loss gradient, both bias gradients, wgrad and dgrad of the narrow last layer in one pass over H_{L-2}
+            LayerPlan& q = m->layers[l - 1];
+            const int D = p.out, K = p.in;
+            head_plan(m, R, &kc, &splits);
+            prof_mark(m, l, 1, 0, s);
+            hipLaunchKernelGGL(head_backward_fn(D), dim3((unsigned)splits), dim3(256), head_lds_bytes(D, K), s, (const float*)p.H, p.ldh,
+                               (int)batch, lag_offset(m, idx_d, batch), (const float*)m->gradp, p.act, (const float*)q.H, q.ldh, K, q.act,
+                               (const float*)(m->params + p.w_off), kc, dz_nxt, m->ld_dz, p.slab, p.bpart, q.bpart);
+            DCV_CHECK_LAUNCH();
+            prof_mark(m, l, 1, 1, s);
+            prof_mark(m, l, 2, 0, s);
+            prof_mark(m, l, 2, 1, s);
+            bblocks = (int)splits;
+            ReduceDesc& rd = ra.l[l];
+            rd.slab = p.slab;
+            rd.bpart = p.bpart;
+            rd.w_off = p.w_off;
+            rd.b_off = p.b_off;
+            rd.w_count = (int64_t)p.out * p.in;
+            rd.out = p.out;
+            rd.splits = (int)splits;
+            rd.bblocks = bblocks;
+            float* tmp = dz_cur;
+            dz_cur = dz_nxt;
+            dz_nxt = tmp;
+            continue;
         }
         Operand A = make_operand(dz_cur, m->ld_dz, p.out);
         Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);

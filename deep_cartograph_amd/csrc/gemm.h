@@ -419,13 +419,13 @@ template <int N>
 __device__ __forceinline__ void vm_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until at most min(MAXY, younger) stages of GL instructions each are still in flight
-template <int MAXY, int GL>
+// wait until at most min(MAXY, younger) stages of GL instructions each (plus EXTRA younger loads) are still in flight
+template <int MAXY, int GL, int EXTRA = 0>
 __device__ __forceinline__ void vm_wait_younger(int64_t younger) {
-    if constexpr (MAXY == 0) vm_wait<0>();
+    if constexpr (MAXY == 0) vm_wait<EXTRA>();
     else {
-        if (younger >= MAXY) vm_wait<MAXY * GL>();
-        else vm_wait_younger<MAXY - 1, GL>(younger);
+        if (younger >= MAXY) vm_wait<MAXY * GL + EXTRA>();
+        else vm_wait_younger<MAXY - 1, GL, EXTRA>(younger);
     }
 }
 
@@ -649,6 +649,21 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         }
 #endif
     };
+    // ---- staged-epilogue geometry (used by the side-operand prefetch below and by the epilogue)
+    constexpr int LDSF = Cfg::NBUF * STAGE;   // floats of LDS the kernel owns
+    constexpr int EPASS = (TM * TN + LDSF - 1) / LDSF;
+    constexpr int RP = TM / (EPASS > 0 ? EPASS : 1);   // rows per pass
+    constexpr bool kStaged = (NB == 1) && (EPASS <= 2) && (TM % EPASS == 0) && (RP % (FM * 32) == 0) && (RP * TN <= LDSF);
+    constexpr int EC4 = TN / 4;                 // 16-byte segments per row
+    constexpr int ERPP = 256 / (EC4 > 256 ? 256 : EC4);   // rows per pass of the store loop
+    constexpr int ENQ = RP / ERPP;              // row segments per thread and epilogue pass
+    // Side operand of the epilogue (the stored activations whose derivative scales a dgrad tile): for a
+    // full tile its EPASS * ENQ row segments are requested before the first stage is awaited, so they
+    // stream in under the main loop instead of in a burst at the end while the matrix pipe idles
+    // (short-K products are otherwise HBM-bound for the length of their epilogue and idle before it).
+    constexpr bool kSidePre = kStaged && Epi::kSide && (EPASS * ENQ <= 16) && ((Cfg::NBUF - 2) * 0 + EPASS * ENQ <= 32);
+    float4 side_pre[kSidePre ? EPASS * ENQ : 1];
+    bool side_ready = false;
     // Two main loops in sequence.  The full stages of a workgroup whose tile is fully in range (the
     // common case) run the pure LDS-DMA loop: no staging registers are live in it, so the compiler has
     // no reason to wait on the vector-memory counter inside the MFMA phase.  Whatever remains -- the
@@ -674,7 +689,21 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         for (int s = 0; s < NBUF - 1; ++s)
             if (s < nst) glds_stage(k_begin + s * KB, s);
         // boundary "-1 -> 0": stage 0 landed and published; every buffer is still free
-        vm_wait_younger<NBUF - 2, GL>(nst - 1);
+        if constexpr (kSidePre) {
+            static_assert((NBUF - 2) * GL + EPASS * ENQ <= 63, "vmcnt range");
+            side_ready = epi.vec && (m0 + TM <= d.M) && (n0 + TN <= d.N);
+            if (side_ready) {
+                const int ec4 = t % EC4, er0 = t / EC4;
+#pragma unroll
+                for (int q = 0; q < EPASS * ENQ; ++q)
+                    side_pre[q] = *reinterpret_cast<const float4*>(epi.side_ptr(m0 + er0 + q * ERPP, n0 + ec4 * 4));
+                vm_wait_younger<NBUF - 2, GL, EPASS * ENQ>(nst - 1);   // the side loads are younger than the stage DMAs
+            } else {
+                vm_wait_younger<NBUF - 2, GL>(nst - 1);
+            }
+        } else {
+            vm_wait_younger<NBUF - 2, GL>(nst - 1);
+        }
         __syncthreads();
 #ifndef DCV_ABL_NOLOAD
         if (NBUF - 1 < nst) glds_stage(k_begin + (NBUF - 1) * KB, NBUF - 1);
@@ -785,10 +814,6 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // gradients for free).
     // When the stage buffers are smaller than the tile (KB = 16) the tile goes through in EPASS row
     // blocks, each written by the waves that own those rows.
-    constexpr int LDSF = Cfg::NBUF * STAGE;   // floats of LDS the kernel owns
-    constexpr int EPASS = (TM * TN + LDSF - 1) / LDSF;
-    constexpr int RP = TM / (EPASS > 0 ? EPASS : 1);   // rows per pass
-    constexpr bool kStaged = (NB == 1) && (EPASS <= 2) && (TM % EPASS == 0) && (RP % (FM * 32) == 0) && (RP * TN <= LDSF);
     DCV_STAMP_AT(2);
     DCV_STAMP_RT(6);
     if constexpr (kStaged) {
@@ -834,6 +859,12 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
                     for (int q = 0; q < EQ; ++q) {
                         const int64_t row = mbase + r0 + (qc + q) * RPP;
+                        if constexpr (kSidePre) {
+                            if (side_ready) {   // requested before the main loop (row segment ep * NQ + qc + q of this thread)
+                                side[q] = side_pre[ep * NQ + qc + q];
+                                continue;
+                            }
+                        }
                         if (fast) side[q] = *reinterpret_cast<const float4*>(epi.side_ptr(row, col));
                         else side[q] = (row < d.M && nvalid > 0) ? load_quad(epi.side_ptr(row, col), nvalid, epi.vec) : make_float4(0.f, 0.f, 0.f, 0.f);
                     }

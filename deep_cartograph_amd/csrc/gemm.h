@@ -816,6 +816,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // blocks, each written by the waves that own those rows.
     DCV_STAMP_AT(2);
     DCV_STAMP_RT(6);
+    static_assert(!Epi::kHead || kStaged, "the fused narrow layer needs the staged epilogue");
     if constexpr (kStaged) {
         float* tile = lds;  // [RP][TN]
         constexpr int C4 = TN / 4;           // 16-byte segments per row
@@ -872,6 +873,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
                 for (int q = 0; q < EQ; ++q) v[q] = *reinterpret_cast<const float4*>(tile + (r0 + (qc + q) * RPP) * TN + c4 * 4);
                 epi.template transform<EQ>(v, side, cc);
+                if constexpr (Epi::kHead) epi.template head<EQ, C4>(v, mbase + r0 + qc * RPP, RPP, col, nvalid, d.M, lane);
                 if (fast) {
 #pragma unroll
                     for (int q = 0; q < EQ; ++q) {

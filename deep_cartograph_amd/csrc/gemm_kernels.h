@@ -46,6 +46,7 @@ __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v
 struct EpiStore {  // C = acc
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
+    static constexpr bool kHead = false;
     float* C;
     int64_t ldc;
     bool vec;
@@ -58,6 +59,7 @@ struct EpiStore {  // C = acc
 struct EpiBiasAct {  // H = act(acc + bias[col])
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
+    static constexpr bool kHead = false;
     float* C;
     int64_t ldc;
     const float* bias;
@@ -80,9 +82,99 @@ struct EpiBiasAct {  // H = act(acc + bias[col])
         C[r * ldc + c] = act_fwd(act, v + (bias ? bias[c] : 0.f));
     }
 };
+// Butterfly reduce-scatter of CUR values over the C4 consecutive lanes that share the rows of a thread
+// group: while the count is even each step halves it (a lane keeps the half selected by its lane bit and
+// adds the partner's copy of that half), odd counts fall back to an all-reduce step.  Afterwards x[i],
+// i < the returned count, holds the full sum of original entry base + i; lanes that differ only in the
+// bits of `dup` hold copies.
+template <int CUR, int OFF, int MAXN>
+__device__ __forceinline__ int butterfly_sum(float (&x)[MAXN], int lane, int& base, int& dup) {
+    if constexpr (OFF >= 1) {
+        if constexpr (CUR % 2 == 0) {
+            constexpr int H = CUR / 2;
+            const bool up = (lane & OFF) != 0;
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                const float send = up ? x[i] : x[i + H];
+                const float keep = up ? x[i + H] : x[i];
+                x[i] = keep + __shfl_xor(send, OFF, 64);
+            }
+            base += up ? H : 0;
+            return butterfly_sum<H, OFF / 2, MAXN>(x, lane, base, dup);
+        } else {
+#pragma unroll
+            for (int i = 0; i < CUR; ++i) x[i] += __shfl_xor(x[i], OFF, 64);
+            dup |= OFF;
+            return butterfly_sum<CUR, OFF / 2, MAXN>(x, lane, base, dup);
+        }
+    } else {
+        return CUR;
+    }
+}
+
+// H = act(acc + bias) as EpiBiasAct, and -- fused -- the narrow Linear that follows it:
+// Z[r][j] = act2(sum_c H[r][c] W2[j][c] + b2[j]), j < D <= DMAX, for a product whose N columns fit one
+// column tile (the whole row of H is in this workgroup).  Saves streaming H once more for 2*D flop per
+// element: a thread's 4-column partial dot products are summed over the lanes that share its rows.
+template <int DMAX>
+struct EpiBiasActHead {
+    static constexpr bool kColSum = false;
+    static constexpr bool kSide = false;
+    static constexpr bool kHead = true;
+    float* C;
+    int64_t ldc;
+    const float* bias;
+    int act;
+    bool vec;
+    const float* W2;   // [D][ldw]
+    int64_t ldw;
+    const float* b2;   // [D] or null
+    int D, act2;
+    float* Z;          // [M][ldz]
+    int64_t ldz;
+    __device__ __forceinline__ float4 colconst(int64_t c, int nvalid) const {
+        return bias ? load_quad(bias + c, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    template <int N>
+    __device__ __forceinline__ void transform(float4 (&v)[N], const float4 (&)[1], const float4& b) const {
+        switch (act) {
+            case DCV_ACT_LEAKY_RELU: map_quads<N>(v, [&](float x, int c, int) { const float z = x + f4c(b, c); return z > 0.f ? z : 0.01f * z; }); break;
+            case DCV_ACT_RELU: map_quads<N>(v, [&](float x, int c, int) { const float z = x + f4c(b, c); return z > 0.f ? z : 0.f; }); break;
+            case DCV_ACT_NONE: map_quads<N>(v, [&](float x, int c, int) { return x + f4c(b, c); }); break;
+            default: map_quads<N>(v, [&](float x, int c, int) { return act_fwd(act, x + f4c(b, c)); }); break;
+        }
+    }
+    // v[q]: columns col..col+3 (nvalid of them in range) of row row0 + q * row_step, after transform()
+    template <int N, int C4>
+    __device__ __forceinline__ void head(const float4 (&v)[N], int64_t row0, int row_step, int64_t col, int nvalid, int64_t M,
+                                         int lane) const {
+        static_assert((C4 & (C4 - 1)) == 0 && C4 <= 32, "lanes per row group");
+        float x[N * DMAX];
+#pragma unroll
+        for (int j = 0; j < DMAX; ++j) {
+            const float4 w = (j < D && nvalid > 0) ? load_quad(W2 + (int64_t)j * ldw + col, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int q = 0; q < N; ++q) x[q * DMAX + j] = fmaf(v[q].x, w.x, fmaf(v[q].y, w.y, fmaf(v[q].z, w.z, v[q].w * w.w)));
+        }
+        int base = 0, dup = 0;
+        const int cnt = butterfly_sum<N * DMAX, C4 / 2, N * DMAX>(x, lane, base, dup);
+        if ((lane & dup) != 0) return;
+#pragma unroll
+        for (int i = 0; i < N * DMAX; ++i) {
+            if (i < cnt) {
+                const int f = base + i, q = f / DMAX, j = f - q * DMAX;
+                const int64_t row = row0 + (int64_t)q * row_step;
+                if (j < D && row < M) Z[row * ldz + j] = act_fwd(act2, x[i] + (b2 ? b2[j] : 0.f));
+            }
+        }
+    }
+    __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
+    __device__ __forceinline__ void one(int, int64_t, int64_t, float) const {}
+};
 struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> bias-gradient partials
     static constexpr bool kColSum = true;
     static constexpr bool kSide = true;
+    static constexpr bool kHead = false;
     float* C;
     int64_t ldc;
     const float* H;
@@ -109,6 +201,7 @@ struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> b
 struct EpiSlab {  // split-K partials: slab[z][which][M][N]
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
+    static constexpr bool kHead = false;
     float* slab;
     int64_t M, N;
     int nb;

@@ -940,12 +940,39 @@ extern "C" int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, 
     return DCV_OK;
 }
 
+// layer l + 1 can ride in the epilogue of layer l: it is narrow and layer l's output fits one column tile
+static bool next_layer_fusable(const dcv_mlp* m, int l) {
+    static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
+    if (off || l + 1 >= m->L) return false;
+    return m->layers[l + 1].out <= 8 && m->layers[l].out <= 128;
+}
+
 // forward through layers [0, n_run) for `rows` logical rows
 static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& rows_map, int64_t rows, int n_run, hipStream_t s) {
     for (int l = 0; l < n_run; ++l) {
         LayerPlan& p = m->layers[l];
         Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
         Operand B = make_operand(m->params + p.w_off, p.in, p.in);
+        if (l + 1 < n_run && next_layer_fusable(m, l)) {
+            // the narrow Linear behind this layer rides in its epilogue (the whole row of H is in the workgroup)
+            LayerPlan& nx = m->layers[l + 1];
+            const bool vec = quad_ok(p.H, p.ldh) && quad_ok(m->params + p.b_off, 4) && quad_ok(m->params + nx.w_off, nx.in);
+            prof_mark(m, l, 0, 0, s);
+            int rc;
+            if (nx.out <= 4) {
+                EpiBiasActHead<4> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
+                rc = launch_gemm<kNT, EpiBiasActHead<4>>(A, B, rows, p.out, p.in, 0, epi, s);
+            } else {
+                EpiBiasActHead<8> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
+                rc = launch_gemm<kNT, EpiBiasActHead<8>>(A, B, rows, p.out, p.in, 0, epi, s);
+            }
+            if (rc) return rc;
+            prof_mark(m, l, 0, 1, s);
+            prof_mark(m, l + 1, 0, 0, s);
+            prof_mark(m, l + 1, 0, 1, s);
+            ++l;
+            continue;
+        }
         EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act, quad_ok(p.H, p.ldh) && quad_ok(m->params + p.b_off, 4)};
         prof_mark(m, l, 0, 0, s);
         int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s);

@@ -98,7 +98,7 @@ def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather):
         else:
             # the loss is invariant to a constant shift of the outputs (TICA removes the mean), so
             # the exact gradient of the last bias is 0: both sides hold rounding noise only
-            assert np.max(np.abs(g[bo:bo + gb.size])) < 1e-5 * max(1.0, np.max(np.abs(gw))), f"layer {l} bias"
+            assert np.max(np.abs(g[bo:bo + gb.size])) < 5e-5 * max(1.0, np.max(np.abs(gw))), f"layer {l} bias"
     eng.close()
 
 

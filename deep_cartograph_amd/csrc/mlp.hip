@@ -207,6 +207,59 @@ __global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict
     }
 }
 
+// The same statistics for D <= 4 outputs with every thread at work: a thread walks whole rows (its pair's
+// 2 D values, 2 D + 2 D^2 float64 accumulators in registers), waves combine by shuffles, the block through
+// LDS -- kFastStatRows pairs per block, so the second-stage sum sees 16 times fewer partials.
+constexpr int kFastStatRows = 2048;
+template <int D>
+__global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __restrict__ F, int64_t ld, int B, int lag_off,
+                                                              double* __restrict__ part) {
+    constexpr int W = 2 * D + 2 * D * D;
+    __shared__ double red[4][W];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double acc[W];
+#pragma unroll
+    for (int o = 0; o < W; ++o) acc[o] = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * kFastStatRows;
+    const int64_t r1 = r0 + kFastStatRows < B ? r0 + kFastStatRows : B;
+    for (int64_t r = r0 + t; r < r1; r += 256) {
+        double a[D], b[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            a[i] = (double)F[r * ld + i];
+            b[i] = (double)F[(r + lag_off) * ld + i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            acc[i] += a[i];
+            acc[D + i] += b[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                acc[2 * D + i * D + j] += a[i] * a[j];
+                acc[2 * D + D * D + i * D + j] += a[i] * b[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < W; ++o) {
+        double v = acc[o];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][o] = v;
+    }
+    __syncthreads();
+    if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+}
+typedef void (*tica_stats_fn_t)(const float*, int64_t, int, int, double*);
+static tica_stats_fn_t tica_stats_rows_fn(int d) {
+    switch (d) {
+        case 1: return tica_stats_rows_kernel<1>;
+        case 2: return tica_stats_rows_kernel<2>;
+        case 3: return tica_stats_rows_kernel<3>;
+        case 4: return tica_stats_rows_kernel<4>;
+        default: return nullptr;
+    }
+}
+
 // dZ_last[r][c] = g[c] * act'(H_last[r][c]): the gradient of s = sum_j cv_j w.r.t. the network output is the
 // same vector for every frame (the layers after the network are affine)
 __global__ __launch_bounds__(256) void seed_grad_kernel(const float* __restrict__ H, int64_t ldh, int64_t rows, int d, int act,
@@ -994,9 +1047,15 @@ extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const 
     if (rc) return rc;
     const LayerPlan& last = m->layers[m->L - 1];
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
-        const int nb = (int)cdiv(batch, kStatBlockRows);
-        hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, last.H,
-                           last.ldh, batch, m->d_out, lag_offset(m, idx_d, batch), m->spart);
+        int nb;
+        if (tica_stats_fn_t fast = tica_stats_rows_fn(m->d_out)) {
+            nb = (int)cdiv(batch, kFastStatRows);
+            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, (const float*)last.H, last.ldh, (int)batch, lag_offset(m, idx_d, batch), m->spart);
+        } else {
+            nb = (int)cdiv(batch, kStatBlockRows);
+            hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, last.H,
+                               last.ldh, batch, m->d_out, lag_offset(m, idx_d, batch), m->spart);
+        }
         DCV_CHECK_LAUNCH();
         hipLaunchKernelGGL(sum_partials_kernel, dim3(m->stats_len), dim3(64), 0, s, m->spart, nb, m->stats_len, m->stats);
         DCV_CHECK_LAUNCH();

@@ -167,6 +167,43 @@ def kmeans_step(P: torch.Tensor, centers: torch.Tensor, labels: torch.Tensor, of
     return acc, md
 
 
+def label_stats(P: torch.Tensor, labels: torch.Tensor, k: int, centers: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[sums (k*d) | counts (k) | sum ||x - c||^2 (k) | sum ||x - c|| (k)] per label, float64 on the device
+    (the last two groups about `centers` when given)."""
+    _require_gpu(P, labels, centers)
+    _check_matrix(P, torch.float64)
+    lib = _lib.load()
+    n, d = P.shape
+    acc = torch.empty(k * d + 3 * k, dtype=torch.float64, device=P.device)
+    ws = _ws(lib.dcv_label_stats_workspace(n, d, k), P.device)
+    check(lib.dcv_label_stats(_ptr(P), n, d, _ptr(labels), _ptr(centers), k, _ptr(acc), _ptr(ws), ws.numel(), _stream()), "dcv_label_stats")
+    return acc
+
+
+def cluster_dist_sums(Q: torch.Tensor, P_sorted: torch.Tensor, start: torch.Tensor) -> torch.Tensor:
+    """S[i][c] = sum_j in cluster c ||Q_i - P_j||; P_sorted holds cluster c in rows [start[c], start[c+1])."""
+    _require_gpu(Q, P_sorted, start)
+    _check_matrix(Q, torch.float64)
+    _check_matrix(P_sorted, torch.float64)
+    lib = _lib.load()
+    nq, d = Q.shape
+    k = start.numel() - 1
+    S = torch.empty(nq, k, dtype=torch.float64, device=Q.device)
+    check(lib.dcv_cluster_dist_sums(_ptr(Q), nq, _ptr(P_sorted), _ptr(start), k, d, _ptr(S), _stream()), "dcv_cluster_dist_sums")
+    return S
+
+
+def silhouette_sum(S: torch.Tensor, qlabels: torch.Tensor, start: torch.Tensor) -> torch.Tensor:
+    """Sum of the silhouette sample values of the queries (1-element float64 device tensor)."""
+    _require_gpu(S, qlabels, start)
+    lib = _lib.load()
+    nq, k = S.shape
+    out = torch.empty(1, dtype=torch.float64, device=S.device)
+    ws = _ws(lib.dcv_silhouette_sum_workspace(nq), S.device)
+    check(lib.dcv_silhouette_sum(_ptr(S), nq, k, _ptr(qlabels), _ptr(start), _ptr(out), _ptr(ws), ws.numel(), _stream()), "dcv_silhouette_sum")
+    return out
+
+
 def nearest_rows(P: torch.Tensor, centers: torch.Tensor, row_offset: int = 0):
     """Per centroid: (distance, global row) of the nearest point (np.linalg.norm, first index on ties)."""
     _require_gpu(P, centers)

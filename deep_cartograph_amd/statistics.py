@@ -206,6 +206,70 @@ def cluster_data(features: np.ndarray, settings: Dict, initial_centroids: np.nda
     raise Exception(f"clustering algorithm {algo} not implemented")
 
 
+def clustering_scores(features: np.ndarray, labels: np.ndarray, comm: Optional[Comm] = None,
+                      silhouette_max_points: Optional[int] = None) -> Tuple[float, float, float]:
+    """(Calinski-Harabasz, Davies-Bouldin, silhouette) of a labelling on the GPU, the definitions of
+    sklearn.metrics the reference calls (statistics.py:73-75).  `features` / `labels` are this rank's
+    block of frames.  CH and DB are two streaming passes (label sums -> means, then dispersions);
+    the silhouette is the exact all-pairs form, O(n^2 d) float64: `silhouette_max_points` (opt-in, a
+    behaviour change with respect to the reference) evaluates it on an evenly strided subset of the
+    query points against all points."""
+    comm = comm or Comm()
+    dev = _device()
+    P = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float64)).to(dev)
+    lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
+    d = P.shape[1]
+    k = int(comm.max_(lab.max().reshape(1).to(torch.int64)).item()) + 1 if comm.active else int(lab.max().item()) + 1
+    if not (1 <= k <= 64) or d > 16:
+        raise NotImplementedError(f"the HIP score kernels support k <= 64, d <= 16 (got k={k}, d={d})")
+    acc = comm.sum_(hip.label_stats(P, lab, k)).cpu().numpy()
+    counts = acc[k * d: k * d + k]
+    n = counts.sum()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        means = acc[: k * d].reshape(k, d) / counts[:, None]
+    means = np.nan_to_num(means)
+    acc = comm.sum_(hip.label_stats(P, lab, k, centers=torch.from_numpy(means).to(dev))).cpu().numpy()
+    ss = acc[k * d + k: k * d + 2 * k]
+    sd = acc[k * d + 2 * k: k * d + 3 * k]
+    present = counts > 0
+    n_labels = int(present.sum())
+    # Calinski-Harabasz (sklearn: extra_disp * (n - k) / (intra_disp * (k - 1)), 1.0 when intra_disp == 0)
+    mean_all = (means * counts[:, None]).sum(axis=0) / n
+    extra = float((counts * ((means - mean_all) ** 2).sum(axis=1)).sum())
+    intra = float(ss.sum())
+    ch = 1.0 if intra == 0.0 else extra * (n - n_labels) / (intra * (n_labels - 1.0))
+    # Davies-Bouldin (sklearn: mean over clusters of max_j (s_i + s_j) / d_ij, 0/0 -> 0)
+    mp = means[present]
+    sp = sd[present] / counts[present]
+    cd = np.sqrt(((mp[:, None, :] - mp[None, :, :]) ** 2).sum(axis=2))
+    if np.allclose(sp, 0) or np.allclose(cd, 0):
+        db = 0.0
+    else:
+        cd[cd == 0] = np.inf
+        db = float(np.mean(np.max((sp[:, None] + sp[None, :]) / cd, axis=1)))
+    # silhouette: all points sorted by cluster (gathered over the ranks), this rank's points as queries
+    P_all = comm.all_gather_rows(P)
+    lab_all = comm.all_gather_rows(lab)
+    order = torch.argsort(lab_all, stable=True)
+    P_sorted = P_all[order].contiguous()
+    start = torch.zeros(k + 1, dtype=torch.int64, device=dev)
+    start[1:] = torch.cumsum(torch.bincount(lab_all.clamp(min=0).to(torch.int64), minlength=k)[:k], dim=0)
+    Q, ql = P, lab
+    if silhouette_max_points is not None and n > silhouette_max_points:
+        stride = int(np.ceil(n / silhouette_max_points))
+        Q, ql = P[::stride].contiguous(), lab[::stride].contiguous()
+    tot = torch.zeros(1, dtype=torch.float64, device=dev)
+    nq = 0
+    chunk = max(1, (1 << 26) // max(k, 1))           # bound the nq x k float64 scratch to 512 MiB
+    for b in range(0, Q.shape[0], chunk):
+        S = hip.cluster_dist_sums(Q[b:b + chunk], P_sorted, start)
+        tot += hip.silhouette_sum(S, ql[b:b + chunk], start)
+        nq += min(chunk, Q.shape[0] - b)
+    tot = comm.sum_(tot)
+    nq = comm.sum_scalar(float(nq), device=dev)
+    return float(ch), float(db), float(tot.item() / nq)
+
+
 def optimize_clustering(features: np.ndarray, settings: Dict):
     """k in search_interval (inclusive): cluster, Calinski-Harabasz / Davies-Bouldin / silhouette,
     min-max normalise each list, best (CH - DB + Sil) / 3 (reference :17-110).  The scores stay
@@ -219,9 +283,14 @@ def optimize_clustering(features: np.ndarray, settings: Dict):
         for N in ks:
             settings["num_clusters"] = N
             labels, centroids = cluster_data(features, settings)
-            ch.append(calinski_harabasz_score(features, labels))
-            db.append(davies_bouldin_score(features, labels))
-            si.append(silhouette_score(features, labels))
+            if settings["algorithm"] == "kmeans":   # scores on the GPU (same definitions: clustering_scores)
+                c_, d_, s_ = clustering_scores(features, labels, silhouette_max_points=settings.get("silhouette_max_points"))
+            else:
+                c_, d_, s_ = (calinski_harabasz_score(features, labels), davies_bouldin_score(features, labels),
+                              silhouette_score(features, labels))
+            ch.append(c_)
+            db.append(d_)
+            si.append(s_)
             results.append((labels, centroids))
         with np.errstate(invalid="ignore", divide="ignore"):
             ch = (ch - np.min(ch)) / (np.max(ch) - np.min(ch))

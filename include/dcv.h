@@ -234,6 +234,28 @@ int dcv_kmeans_step(const double* P_d, int64_t n, int32_t d, const double* offse
                     const double* centers_d, int32_t k, int32_t* labels_d, double* acc_d, double* mindist_d /* n or NULL */,
                     void* ws_d, size_t ws_bytes, void* stream);
 
+/* ---------------------------------------------------------------- k-selection scores
+ * Replace sklearn.metrics calinski_harabasz_score / davies_bouldin_score / silhouette_score as called
+ * by statistics.optimize_clustering, statistics.py:73-75, on points P (n x d float64, d <= 16) and
+ * int32 labels in [0, k), k <= 64 (other labels are ignored).
+ * dcv_label_stats: acc_d = [sums k*d | counts k | sum ||x - c_label||^2 k | sum ||x - c_label|| k]
+ * (float64; the last two groups about centers_d (k x d) when given, zero otherwise) -- two calls give
+ * the label means and then the dispersions both scores are built from; every group combines over
+ * shards by addition.
+ * dcv_cluster_dist_sums: S[i][c] = sum over the points j of cluster c of ||Q_i - P_j|| for nq query
+ * points against the points sorted by cluster (cluster c = rows [start[c], start[c+1]) of Psorted_d;
+ * start_d holds k + 1 int64).  The exact all-pairs silhouette: O(nq * n * d) float64.
+ * dcv_silhouette_sum: sum_d[0] = sum of the silhouette sample values of the nq queries (labels
+ * qlabels_d), sklearn's definition incl. 0 for singleton clusters; divide by n for the score. */
+size_t dcv_label_stats_workspace(int64_t n, int32_t d, int32_t k);
+int dcv_label_stats(const double* P_d, int64_t n, int32_t d, const int32_t* labels_d, const double* centers_d /* k*d or NULL */,
+                    int32_t k, double* acc_d, void* ws_d, size_t ws_bytes, void* stream);
+int dcv_cluster_dist_sums(const double* Q_d, int64_t nq, const double* Psorted_d, const int64_t* start_d, int32_t k, int32_t d,
+                          double* S_d /* nq x k */, void* stream);
+size_t dcv_silhouette_sum_workspace(int64_t nq);
+int dcv_silhouette_sum(const double* S_d, int64_t nq, int32_t k, const int32_t* qlabels_d, const int64_t* start_d,
+                       double* sum_d, void* ws_d, size_t ws_bytes, void* stream);
+
 /* Replaces statistics.find_centroids, statistics.py:370-377: for each of the k centroids the
  * index of the nearest of ALL n points under np.linalg.norm (ties -> lowest index).
  * best_d receives k pairs [distance (float64) | row (float64-encoded int64 is avoided:

@@ -365,3 +365,33 @@ def test_kmeans_two_ranks_match_single_process(tmp_path):
         np.testing.assert_array_equal(np.concatenate([p[f"{tag}_labels"] for p in parts]), ref[0])
         for p in parts:
             np.testing.assert_allclose(p[f"{tag}_centers"], ref[1], rtol=0, atol=1e-12)
+
+
+def test_clustering_scores_match_sklearn(golden_proj):
+    """Calinski-Harabasz, Davies-Bouldin (streaming passes) and the exact all-pairs silhouette of the HIP
+    kernels against sklearn.metrics on the reference's projected CVs and a seeded mixture; tolerance 1e-9 relative
+    (float64 both sides, different summation orders; sklearn's pairwise distances use the dot-product expansion)."""
+    from sklearn.cluster import KMeans
+    from sklearn.metrics import calinski_harabasz_score, davies_bouldin_score, silhouette_score
+
+    from deep_cartograph_amd import statistics
+
+    rng = np.random.default_rng(11)
+    cent = rng.uniform(-3, 3, (6, 3))
+    mix = np.round(np.concatenate([c + 0.5 * rng.standard_normal((500 + 61 * i, 3)) for i, c in enumerate(cent)]), 4)
+    cases = [(golden_proj["tica"], 4), (golden_proj["pca"], 7), (mix, 6), (mix[:, :1].copy(), 3)]
+    for P, k in cases:
+        lab = KMeans(n_clusters=k, n_init=2, random_state=0).fit_predict(P).astype(np.int32)
+        ch, db, si = statistics.clustering_scores(P.copy(), lab)
+        np.testing.assert_allclose(ch, calinski_harabasz_score(P, lab), rtol=1e-9)
+        np.testing.assert_allclose(db, davies_bouldin_score(P, lab), rtol=1e-9)
+        np.testing.assert_allclose(si, silhouette_score(P, lab), rtol=1e-9, atol=1e-12)
+    # a singleton cluster scores 0 for its sample (sklearn convention)
+    P = mix[:300].copy()
+    lab = np.zeros(300, dtype=np.int32)
+    lab[150:] = 1
+    lab[0] = 2
+    ch, db, si = statistics.clustering_scores(P, lab)
+    np.testing.assert_allclose(si, silhouette_score(P, lab), rtol=1e-9)
+    np.testing.assert_allclose(ch, calinski_harabasz_score(P, lab), rtol=1e-9)
+    np.testing.assert_allclose(db, davies_bouldin_score(P, lab), rtol=1e-9)

@@ -113,7 +113,26 @@ def c5_parts(n=20_000_000, d=4, k=6):
     return out
 
 
+def f4_scores(n=1_000_000, d=4, k=6):
+    """k-selection scores on a seeded mixture: two streaming passes + the exact all-pairs silhouette."""
+    rng = np.random.Generator(np.random.PCG64(7))
+    mu = rng.uniform(-0.8, 0.8, size=(k, d))
+    lab = rng.integers(0, k, n)
+    P = np.round(mu[lab] + 0.08 * rng.standard_normal((n, d)), 4)
+    labels = lab.astype(np.int32)
+    Pd, ld = torch.from_numpy(P).cuda(), torch.from_numpy(labels).cuda()
+    t = timed(lambda: hip.label_stats(Pd, ld, k))
+    out = {"config": f"f4 scores, {n}x{d} float64, k={k}", "label_stats_ms": t * 1e3, "label_stats_GBps": (8.0 * d + 4.0) * n / t / 1e9}
+    sync()
+    t0 = time.perf_counter()
+    ch, db, si = statistics.clustering_scores(P, labels)
+    sync()
+    dt = time.perf_counter() - t0
+    out.update({"scores_s": dt, "pair_distances_per_s": float(n) * n / dt, "calinski_harabasz": ch, "davies_bouldin": db, "silhouette": si})
+    return out
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c3", "c2", "c5"]
+    which = sys.argv[1:] or ["c3", "c2", "c5", "f4"]
     for w in which:
-        print(json.dumps({"c3": c3, "c2": c2, "c5": c5_parts}[w]()), flush=True)
+        print(json.dumps({"c3": c3, "c2": c2, "c5": c5_parts, "f4": f4_scores}[w]()), flush=True)

@@ -287,20 +287,53 @@ class CVCalculator(ABC):
         return self.cv_range
 
     def write_plumed_files(self, topology: Optional[str], output_folder: str, waypoint_structures=None):
-        """PLUMED input for this CV.  Without a topology the reference returns early
-        (cv_calculator.py:569-571); with one, the CV definition lines are written: COMBINE for
-        linear CVs, PYTORCH_MODEL for neural ones (assembler.py:333-431)."""
+        """PLUMED input that tracks this CV (reference cv_calculator.py:545-681 -> ComputeCVBuilder).
+        Without a topology the reference returns early (:569-571).  Written here: the header, the CV
+        section exactly as the reference's assembler composes it (assembler.py:333-431 with
+        command.combine / command.pytorch_model, command.py:357-420, 1149-1178) and the PRINT line
+        (command.py:520-564, traj_stride 1), zipped as plumed_<cv>_unbiased.zip together with the
+        TorchScript weights of a neural CV.  The MOLINFO / WHOLEMOLECULES / per-feature commands and
+        the feature-name translation between topologies need MDAnalysis (out of scope): the feature
+        labels are used as the PLUMED argument names, and the enhanced-sampling input is not built."""
         if topology is None:
-            logger.warning("No topology given: PLUMED files are not written.")
+            logger.warning("Topology not provided. Skipping PLUMED files creation.")
             return
         os.makedirs(output_folder, exist_ok=True)
-        path = os.path.join(output_folder, f"plumed_{self.cv_name}.dat")
+        self.plumed_files = []
+        if self.get_cv_type() == "non-linear":
+            self.weights_path = os.path.join(output_folder, f"{self.cv_name}_weights.pt")
+            self.save_weights(self.weights_path)
+            self.plumed_files.append(self.weights_path)
+        path = os.path.join(output_folder, f"plumed_input_{self.cv_name}.dat")
+        text = "# PLUMED input file generated with Deep Cartograph\n"
+        text += self.plumed_cv_lines()
+        text += "\n" + plumed_print(self.plumed_cv_labels(), f"{self.cv_name}_out.dat", 1)
         with open(path, "w") as f:
-            f.write(self.plumed_cv_lines())
+            f.write(text)
         self.plumed_files.append(path)
+        zip_files(os.path.join(output_folder, f"plumed_{self.cv_name}_unbiased.zip"), *self.plumed_files)
+        remove_files(*self.plumed_files)
 
     def plumed_cv_lines(self) -> str:
         raise NotImplementedError
+
+    def plumed_cv_labels(self) -> List[str]:
+        raise NotImplementedError
+
+
+def plumed_combine(label: str, arguments, coefficients=None, parameters=None, periodic: bool = False) -> str:
+    """PLUMED COMBINE line in the reference's format (command.py:357-420): %.17g coefficients / parameters."""
+    line = label + ": COMBINE ARG=" + ",".join(arguments)
+    if coefficients is not None:
+        line += " COEFFICIENTS=" + ",".join(f"{c:.17g}" for c in coefficients)
+    if parameters is not None:
+        line += " PARAMETERS=" + ",".join(f"{a:.17g}" for a in parameters)
+    return line + (" PERIODIC=YES" if periodic else " PERIODIC=NO") + "\n"
+
+
+def plumed_print(arguments, file_path: str, stride: int = 1, fmt: str = "%.4f") -> str:
+    """PLUMED PRINT line in the reference's format (command.py:520-564)."""
+    return "PRINT ARG=" + ",".join(arguments) + " FILE=" + file_path + " STRIDE=" + str(stride) + f" FMT={fmt}\n"
 
 
 # ======================================================================================= linear
@@ -429,13 +462,32 @@ class LinearCalculator(CVCalculator):
         return delta, C0, Ct, n_pairs
 
     def plumed_cv_lines(self) -> str:
-        lines = []
-        names = self.features_ref_labels
-        for i in range(self.cv_dimension):
-            coef = self.cv[:, i] / self.features_norm_range
-            lines.append(f"{self.cv_name}_{i}: COMBINE ARG={','.join(names)} COEFFICIENTS={','.join('%.17g' % c for c in coef)} "
-                         f"PARAMETERS={','.join('%.17g' % m for m in self.features_norm_mean)} PERIODIC=NO")
-        return "\n".join(lines) + "\n"
+        """The linear CV section of the reference's assembler (assembler.py:333-381): one COMBINE per
+        normalised feature, one per CV component over them, one per min-max normalised component."""
+        text = ""
+        feats = list(self.features_ref_labels)
+        if self.feats_norm_mode is not None:
+            text += "\n# Normalized features\n"
+            normalized = []
+            for i, feat in enumerate(feats):
+                text += plumed_combine(f"feat_{i}", [feat], [1 / self.features_norm_range[i]], [self.features_norm_mean[i]])
+                normalized.append(f"feat_{i}")
+        else:
+            normalized = feats
+        text += "\n# Collective variable\n"
+        for i in range(self.cv.shape[1]):
+            text += plumed_combine(f"{self.cv_name}_{i}", normalized, self.cv[:, i])
+        # reference: offset = (min + max) / 2, scale = 2 / (max - min) -- the same numbers as cv_norm_mean and
+        # 1 / cv_norm_range (halving is exact), which a model loaded from model.zip also carries
+        offset = np.asarray(self.cv_norm_mean, dtype=np.float64)
+        scale = 1.0 / np.asarray(self.cv_norm_range, dtype=np.float64)
+        text += "\n# Normalized Collective variable\n"
+        for i in range(self.cv.shape[1]):
+            text += plumed_combine(f"norm_{self.cv_name}_{i}", [f"{self.cv_name}_{i}"], [scale[i]], [offset[i]])
+        return text
+
+    def plumed_cv_labels(self) -> List[str]:
+        return [f"norm_{self.cv_name}_{i}" for i in range(self.cv.shape[1])]
 
 
 class PCACalculator(LinearCalculator):
@@ -925,7 +977,12 @@ class NonLinear(CVCalculator):
         return "non-linear"
 
     def plumed_cv_lines(self) -> str:
-        return f"{self.cv_name}: PYTORCH_MODEL FILE={self.weights_path} ARG={','.join(self.features_ref_labels)}\n"
+        """The non-linear CV section (assembler.py:408-422): normalisations live inside the TorchScript model."""
+        return ("\n# Collective variable\n" + f"{self.cv_name}: PYTORCH_MODEL FILE={os.path.abspath(self.weights_path)} "
+                f"ARG={','.join(self.features_ref_labels)}\n")
+
+    def plumed_cv_labels(self) -> List[str]:
+        return [f"{self.cv_name}.node-{i}" for i in range(self.cv_dimension)]
 
 
 class AECalculator(NonLinear):

@@ -72,6 +72,32 @@ def test_pca_golden(features, golden_linear, golden_proj, tmp_path):
     assert (tmp_path / "pca" / "sensitivity_analysis" / "sensitivity_analysis_1" / "sensitivity_analysis.csv").exists()
 
 
+def test_plumed_input_of_a_linear_cv(features, tmp_path):
+    """write_plumed_files: the CV section the reference's assembler writes (assembler.py:333-381) evaluates, as PLUMED
+    COMBINE arithmetic, to the calculator's own projection."""
+    X, names = features
+    calc = make_calc("pca", tmp_path)
+    calc.set_training_matrix(X.copy(), names)
+    df = calc.run(2)
+    calc.write_plumed_files("topology.pdb", str(tmp_path / "plumed"))
+    with zipfile.ZipFile(tmp_path / "plumed" / "plumed_pca_unbiased.zip") as z:
+        text = z.read("plumed_input_pca.dat").decode()
+    lines = [l for l in text.splitlines() if l and not l.startswith("#")]
+    assert text.startswith("# PLUMED input file generated with Deep Cartograph\n\n# Normalized features\nfeat_0: COMBINE ARG=" + names[0])
+    assert lines[-1] == "PRINT ARG=norm_pca_0,norm_pca_1 FILE=pca_out.dat STRIDE=1 FMT=%.4f"
+    assert len(lines) == len(names) + 2 + 2 + 1
+    vals = {n: X[:, i].astype(np.float64) for i, n in enumerate(names)}      # evaluate the COMBINE lines
+    for l in lines[:-1]:
+        label, rest = l.split(": COMBINE ")
+        kw = dict(tok.split("=") for tok in rest.split())
+        args = kw["ARG"].split(",")
+        coef = [float(c) for c in kw["COEFFICIENTS"].split(",")]
+        par = [float(a) for a in kw["PARAMETERS"].split(",")] if "PARAMETERS" in kw else [0.0] * len(args)
+        vals[label] = sum(c * (vals[a] - p) for a, c, p in zip(args, coef, par))
+    out = np.stack([vals["norm_pca_0"], vals["norm_pca_1"]], axis=1)
+    np.testing.assert_allclose(out, df.to_numpy(), atol=5e-6)
+
+
 def test_reference_model_zips_project_to_goldens(features, golden_linear, golden_proj, tmp_path):
     """a14/a16: the arrays of the reference's bundled linear model.zip files, written in the
     reference layout, load through CVCalculator.load and reproduce the golden CSVs."""

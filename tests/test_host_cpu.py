@@ -227,6 +227,18 @@ def test_sharded_reductions_world2(tmp_path):
         assert (tmp_path / f"ok_{r}").read_text() == "1"
 
 
+def test_plumed_command_text():
+    """COMBINE / PRINT lines in the reference's text format (plumed/command.py:357-420, 520-564: %.17g coefficients and
+    parameters, PERIODIC keyword, trailing newline).  Expected strings written out by hand from that format."""
+    from deep_cartograph_amd.cv_calculator import plumed_combine, plumed_print
+
+    assert plumed_combine("feat_0", ["d1"], [1 / 0.25], [0.1]) == "feat_0: COMBINE ARG=d1 COEFFICIENTS=4 PARAMETERS=0.10000000000000001 PERIODIC=NO\n"
+    assert plumed_combine("pca_1", ["feat_0", "feat_1"], np.array([0.5, -1 / 3])) == \
+        "pca_1: COMBINE ARG=feat_0,feat_1 COEFFICIENTS=0.5,-0.33333333333333331 PERIODIC=NO\n"
+    assert plumed_combine("c", ["a"], periodic=True) == "c: COMBINE ARG=a PERIODIC=YES\n"
+    assert plumed_print(["norm_pca_0", "norm_pca_1"], "pca_out.dat", 1) == "PRINT ARG=norm_pca_0,norm_pca_1 FILE=pca_out.dat STRIDE=1 FMT=%.4f\n"
+
+
 def test_calculators_refuse_cpu():
     from deep_cartograph_amd._lib import DcvError
     from deep_cartograph_amd.cv_calculator import cv_calculators_map

@@ -55,10 +55,61 @@ def _read_matrix(path: str, start: int, stop: Optional[int], stride: int) -> Tup
         if arr.shape[1] != len(names):
             raise ValueError(f"{path}: {arr.shape[1]} columns but {len(names)} names")
         return arr[start:stop:stride], names
+    return _read_text(path, names)[start:stop:stride], names
+
+
+PARALLEL_PARSE_MIN_BYTES = 64 << 20   # text files above this size are parsed by a pool of processes
+
+
+def _parse_text_range(args) -> np.ndarray:
+    """Worker: rows of the byte range [begin, end) of a COLVAR text file (the range starts at a line start)."""
+    import io
+
     import pandas as pd
 
-    df = pd.read_csv(path, sep=r"\s+", dtype=np.float32, comment="#", header=None, names=names)
-    return df.iloc[start:stop:stride].to_numpy(dtype=np.float32), names
+    path, begin, end, ncols = args
+    with open(path, "rb") as f:
+        f.seek(begin)
+        blob = f.read(end - begin)
+    if not blob.strip():
+        return np.empty((0, ncols), dtype=np.float32)
+    df = pd.read_csv(io.BytesIO(blob), sep=r"\s+", dtype=np.float32, comment="#", header=None, names=list(range(ncols)))
+    return df.to_numpy(dtype=np.float32)
+
+
+def _line_aligned_ranges(path: str, parts: int):
+    """Cut the file into `parts` byte ranges that begin at line starts (rows keep their order)."""
+    size = os.path.getsize(path)
+    cuts = [0]
+    with open(path, "rb") as f:
+        for i in range(1, parts):
+            f.seek(max(cuts[-1], i * size // parts))
+            f.readline()               # finish the line the cut fell into
+            pos = f.tell()
+            if pos >= size:
+                break
+            if pos > cuts[-1]:
+                cuts.append(pos)
+    cuts.append(size)
+    return [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1) if cuts[i + 1] > cuts[i]]
+
+
+def _read_text(path: str, names: Sequence[str], workers: Optional[int] = None, min_bytes: Optional[int] = None) -> np.ndarray:
+    """All rows x all columns (float32) of a PLUMED COLVAR text file.  The reference parses with one
+    `pd.read_csv(sep='\\s+')` (colvars.py:383); at 10M x 512 that is ~50 GB of text, so large files are cut into
+    line-aligned byte ranges parsed by a process pool (same parser, same values, rows in file order)."""
+    import pandas as pd
+
+    min_bytes = PARALLEL_PARSE_MIN_BYTES if min_bytes is None else min_bytes
+    workers = workers or min(16, os.cpu_count() or 1)
+    if workers <= 1 or os.path.getsize(path) < min_bytes:
+        return pd.read_csv(path, sep=r"\s+", dtype=np.float32, comment="#", header=None, names=list(names)).to_numpy(dtype=np.float32)
+    from concurrent.futures import ProcessPoolExecutor
+
+    ranges = _line_aligned_ranges(path, workers * 4)
+    with ProcessPoolExecutor(max_workers=workers) as pool:
+        blocks = list(pool.map(_parse_text_range, [(path, b, e, len(names)) for b, e in ranges]))
+    return np.concatenate(blocks, axis=0)
 
 
 def load_feature_matrix(colvars_paths: Union[str, Sequence[str]], features_list: Optional[Sequence[str]] = None,

@@ -227,6 +227,30 @@ def test_sharded_reductions_world2(tmp_path):
         assert (tmp_path / f"ok_{r}").read_text() == "1"
 
 
+def test_parallel_text_parse_matches_serial(tmp_path):
+    """the process-pool COLVAR parser returns exactly the rows of the single pd.read_csv the reference uses,
+    in file order, including a comment line in the middle and a missing final newline."""
+    from deep_cartograph_amd import colvars
+
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((5003, 7)).astype(np.float32)
+    names = ["time"] + [f"d{i}" for i in range(6)]
+    path = tmp_path / "c.dat"
+    with open(path, "w") as f:
+        f.write("#! FIELDS " + " ".join(names) + "\n")
+        for i, row in enumerate(X):
+            if i == 2500:
+                f.write("#! SET something 1\n")
+            f.write(" " + " ".join("%.6f" % v for v in row) + ("\n" if i < len(X) - 1 else ""))
+    serial = colvars._read_text(str(path), names, workers=1)
+    par = colvars._read_text(str(path), names, workers=3, min_bytes=0)
+    assert serial.shape == (5003, 7) and par.dtype == np.float32
+    np.testing.assert_array_equal(par, serial)
+    Xl, kept, _ = colvars.load_feature_matrix(str(path), stride=2)
+    np.testing.assert_array_equal(Xl, serial[::2, 1:])
+    assert kept == names[1:]
+
+
 def test_plumed_command_text():
     """COMBINE / PRINT lines in the reference's text format (plumed/command.py:357-420, 520-564: %.17g coefficients and
     parameters, PERIODIC keyword, trailing newline).  Expected strings written out by hand from that format."""

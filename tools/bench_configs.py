@@ -113,6 +113,49 @@ def c5_parts(n=20_000_000, d=4, k=6):
     return out
 
 
+def c5_pipeline(n=2_000_000, F=1024, epochs=2, k=6):
+    """C5 end to end on one GPU at a reduced frame count: Deep-TICA 1024-256-128-4 fit (run(): train, normalise CV,
+    project the training frames, export, sensitivity analysis), '%.4f' rounding seam, k-means (explicit init and
+    k-means++), centroid search, k-selection scores."""
+    import pandas as pd
+
+    X = synth_features(n, F, k_slow=4, device="cuda")
+    cfg = {"dimension": 4, "lag_time": 10, "features_normalization": "mean_std", "tica_regularization": 1e-6,
+           "architecture": {"encoder": {"layers": [256, 128], "activation": ["leaky_relu", "leaky_relu"]}},
+           "training": {"general": {"num_tries": 1, "seed": 42, "lengths": [0.8, 0.2], "batch_size": 65536, "max_epochs": epochs,
+                                    "shuffle": False, "random_split": False, "check_val_every_n_epoch": 1, "save_check_every_n_epoch": 1},
+                        "early_stopping": {"patience": 100, "min_delta": 0.0}, "optimizer": {"name": "Adam", "kwargs": {"lr": 1e-3}},
+                        "lr_scheduler": None, "model_to_save": "last", "save_loss": False}}
+    out = {"config": f"C5 pipeline, {n}x{F}, Deep-TICA {F}-256-128-4 ({epochs} epochs, batch 65536) + project + k-means k={k}"}
+    calc = cv_calculators_map["deep_tica"](cfg, "/tmp/dcv_bench_c5")
+    t0 = time.perf_counter()
+    calc.set_training_matrix(X)
+    sync()
+    out["load_stats_normalise_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    df = calc.run(4)
+    sync()
+    out["run_s"] = time.perf_counter() - t0
+    out["valid_loss"] = calc.metrics["valid_loss"]
+    P = np.round(df.to_numpy(dtype=np.float64), 4)              # the '%.4f' CSV seam
+    init = P[np.linspace(0, len(P) - 1, k).astype(int)].copy()
+    t0 = time.perf_counter()
+    lab, cen = statistics.kmeans_clustering(P, k, 1, initial_centroids=init)
+    out["kmeans_explicit_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lab2, cen2 = statistics.kmeans_clustering(P, k, 1)
+    out["kmeans_plusplus_s"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    marked = statistics.find_centroids(pd.DataFrame(P, columns=list(df.columns)), cen, list(df.columns))
+    out["find_centroids_s"] = time.perf_counter() - t0
+    out["centroid_rows"] = int(marked["centroid"].sum())
+    t0 = time.perf_counter()
+    out["scores_ch_db_sil"] = statistics.clustering_scores(P, lab, silhouette_max_points=200_000)
+    out["scores_s"] = time.perf_counter() - t0
+    out["cluster_sizes"] = np.bincount(lab, minlength=k).tolist()
+    return out
+
+
 def f4_scores(n=1_000_000, d=4, k=6):
     """k-selection scores on a seeded mixture: two streaming passes + the exact all-pairs silhouette."""
     rng = np.random.Generator(np.random.PCG64(7))
@@ -135,4 +178,4 @@ def f4_scores(n=1_000_000, d=4, k=6):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3", "c2", "c5", "f4"]
     for w in which:
-        print(json.dumps({"c3": c3, "c2": c2, "c5": c5_parts, "f4": f4_scores}[w]()), flush=True)
+        print(json.dumps({"c3": c3, "c2": c2, "c5": c5_parts, "c5p": c5_pipeline, "f4": f4_scores}[w]()), flush=True)

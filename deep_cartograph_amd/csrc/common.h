@@ -37,5 +37,9 @@ constexpr int kWave = 64;  // gfx950 wavefront
 
 // Number of CUs of the current device (cached).
 int num_cus();
+// arithmetic of the matrix products: false = FP32-input MFMA, true = FP32-accurate split products on the BF16
+// matrix pipe (default; dcv_set_gemm_mode / environment DCV_GEMM_MODE=native|split)
+bool gemm_split();
+void set_gemm_split(bool on);
 
 }  // namespace dcv

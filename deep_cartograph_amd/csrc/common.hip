@@ -1,5 +1,6 @@
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace dcv {
 static thread_local char g_err[512] = "";
@@ -20,7 +21,24 @@ int num_cus() {
     cached = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     return cached;
 }
+
+static int g_gemm_split = -1;   // -1: not decided yet (environment, else the default)
+bool gemm_split() {
+    if (g_gemm_split < 0) {
+        const char* e = getenv("DCV_GEMM_MODE");
+        g_gemm_split = (e && strcmp(e, "native") == 0) ? 0 : 1;
+    }
+    return g_gemm_split == 1;
+}
+void set_gemm_split(bool on) { g_gemm_split = on ? 1 : 0; }
 }  // namespace dcv
+
+extern "C" int dcv_set_gemm_mode(int mode) {
+    DCV_REQUIRE(mode == DCV_GEMM_NATIVE_F32 || mode == DCV_GEMM_SPLIT_BF16X6, "dcv_set_gemm_mode: unknown mode %d", mode);
+    dcv::set_gemm_split(mode == DCV_GEMM_SPLIT_BF16X6);
+    return DCV_OK;
+}
+extern "C" int dcv_get_gemm_mode(void) { return dcv::gemm_split() ? DCV_GEMM_SPLIT_BF16X6 : DCV_GEMM_NATIVE_F32; }
 
 extern "C" int dcv_abi_version(void) { return DCV_ABI_VERSION; }
 extern "C" const char* dcv_last_error(void) { return dcv::g_err; }

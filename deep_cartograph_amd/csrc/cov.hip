@@ -96,12 +96,16 @@ extern "C" int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int6
                        n_pairs, F, lag, a, b);
     DCV_CHECK_LAUNCH();
 
+    // Always the FP32-input MFMA, whatever dcv_set_gemm_mode says: a covariance is a sum of thousands of same-sign
+    // products per accumulator and the BF16 matrix pipe adds into its accumulator by truncation -- measured bias
+    // -1e-5 relative at 4096 rows (tools/split_bench.hip) against an unbiased +-3e-6 here, and TICA eigenvectors are
+    // held to 1e-5.
     const Operand op = make_operand(X_d, ld, F, identity_rows(), shift_d);
     EpiSlab epi{slab, F, F, p.nb, 0, quad_ok(slab, F)};
     if (p.nb == 2)
-        rc = launch_gemm_cfg<kTN, CfgCov, 2, EpiSlab>(op, op, lag, F, F, n_pairs, p.k_chunk, epi, s);
+        rc = launch_gemm_cfg<kTN, CfgCovT<false>, 2, EpiSlab>(op, op, lag, F, F, n_pairs, p.k_chunk, epi, s);
     else
-        rc = launch_gemm_cfg<kTN, CfgBig, 1, EpiSlab>(op, op, 0, F, F, n_pairs, p.k_chunk, epi, s);
+        rc = launch_gemm_cfg<kTN, CfgBigT<false>, 1, EpiSlab>(op, op, 0, F, F, n_pairs, p.k_chunk, epi, s);
     if (rc) return rc;
     const int64_t FF = (int64_t)F * F;
     hipLaunchKernelGGL(cov_reduce_kernel, dim3((unsigned)cdiv(FF, 256)), dim3(256), 0, s, slab, p.splits, p.nb, FF, A, B);

@@ -48,6 +48,32 @@ __device__ unsigned long long g_stamp[8 * 8192];
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------ FP32-accurate products on the BF16 pipe
+// x = x1 + x2 + x3 with three bf16 pieces (truncation split: 8 + 8 + 8 mantissa bits, every residual exact
+// in fp32), x*y ~ x1y1 + x1y2 + x2y1 + x2y2 + x1y3 + x3y1: each bf16 product is exact in the fp32
+// accumulator and the dropped terms (x2y3, x3y2, x3y3) are <= 2^-23 |xy| -- the size of an fp32 product's own
+// rounding.  Six v_mfma_f32_32x32x16_bf16 (16 passes each would be 8 fp32-input MFMAs of 64 cycles: 512 cycles;
+// the six bf16 ones take 192) per 32x32x16 block; measured error against float64 is at or below that of the
+// FP32-input MFMA path (tools/split_bench.hip, tests/test_kernels_gpu.py).
+// split3: the three planes of 8 floats, plane p as 4 dwords of 2 bf16 (element 2i in the low half).
+__device__ __forceinline__ void split3(const float (&x)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a = __float_as_uint(x[2 * i]), b = __float_as_uint(x[2 * i + 1]);
+        p1[i] = __builtin_amdgcn_perm(b, a, 0x07060302);   // [hi16(b) : hi16(a)]
+        const float ra = x[2 * i] - __uint_as_float(a & 0xFFFF0000u);
+        const float rb = x[2 * i + 1] - __uint_as_float(b & 0xFFFF0000u);
+        const unsigned a2 = __float_as_uint(ra), b2 = __float_as_uint(rb);
+        p2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302);
+        const float sa = ra - __uint_as_float(a2 & 0xFFFF0000u);
+        const float sb = rb - __uint_as_float(b2 & 0xFFFF0000u);
+        p3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302);
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
 enum GemmMode { kNT = 0, kNN = 1, kTN = 2 };
 
@@ -90,9 +116,12 @@ struct GemmDims {
 
 // NBUF: LDS stage buffers of the pure-DMA main loop (a ring: NBUF-1 stages in flight ahead of the
 // one being multiplied); the register-staged loop always double-buffers in the first two.
-template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_, int NBUF_ = 2>
+// SPLIT: FP32-accurate products on the BF16 matrix pipe (see split3 / mfma16 below) instead of the
+// FP32-input MFMA.
+template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_, int NBUF_ = 2, bool SPLIT_ = false>
 struct TileCfg {
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, FM = FM_, FN = FN_, KB = KB_, NBUF = NBUF_;
+    static constexpr bool SPLIT = SPLIT_;
     static_assert(NBUF >= 2 && NBUF <= 8, "NBUF");
     static constexpr int TM = WAVES_M * FM * 32;
     static constexpr int TN = WAVES_N * FN * 32;
@@ -376,6 +405,11 @@ __device__ __forceinline__ v4f frag_mmajor(const float* lds, int rb, int g, int 
     const int chunk = 2 * g + (lane >> 5);
     return *reinterpret_cast<const v4f*>(lds + mmajor_off<KB>(row, chunk));
 }
+// MMAJOR: 16-byte chunk `chunk` (4 consecutive k) of row rb + (lane & 31)
+template <int KB>
+__device__ __forceinline__ v4f frag_mmajor_chunk(const float* lds, int rb, int chunk, int lane) {
+    return *reinterpret_cast<const v4f*>(lds + mmajor_off<KB>(rb + (lane & 31), chunk));
+}
 // KMAJOR fragment of the 32 columns starting at `cb`, k-group g, step s.
 template <int T>
 __device__ __forceinline__ float frag_kmajor(const float* lds, int cb, int g, int s, int lane) {
@@ -596,6 +630,66 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(f.b[b][j]));
         }
     };
+    // ---- SPLIT path: one 16-deep step.  Lane l holds, per 32-row operand tile, the 8 contraction values
+    // k = 16 s + 8 (l >> 5) + e (e = 0..7) of row / column l & 31 -- the operand layout of
+    // v_mfma_f32_32x32x16_bf16 -- as fp32; they are split into three bf16 planes in registers.
+    struct Frags8 {
+        float a[FM][8];
+        float b[NB][FN][8];
+    };
+    auto read_frags8 = [&](Frags8& f, const float* la, const float* lb, int s) {
+        const int h = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            if constexpr (A_MM) {
+                const v4f u = frag_mmajor_chunk<KB>(la, wm + i * 32, 4 * s + 2 * h, lane);
+                const v4f v = frag_mmajor_chunk<KB>(la, wm + i * 32, 4 * s + 2 * h + 1, lane);
+                f.a[i][0] = u.x; f.a[i][1] = u.y; f.a[i][2] = u.z; f.a[i][3] = u.w;
+                f.a[i][4] = v.x; f.a[i][5] = v.y; f.a[i][6] = v.z; f.a[i][7] = v.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f.a[i][e] = la[(16 * s + 8 * h + e) * TM + wm + i * 32 + (lane & 31)];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (B_MM) {
+                    const v4f u = frag_mmajor_chunk<KB>(lb, wn + j * 32, 4 * s + 2 * h, lane);
+                    const v4f v = frag_mmajor_chunk<KB>(lb, wn + j * 32, 4 * s + 2 * h + 1, lane);
+                    f.b[b][j][0] = u.x; f.b[b][j][1] = u.y; f.b[b][j][2] = u.z; f.b[b][j][3] = u.w;
+                    f.b[b][j][4] = v.x; f.b[b][j][5] = v.y; f.b[b][j][6] = v.z; f.b[b][j][7] = v.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f.b[b][j][e] = lb[b * B_SZ + (16 * s + 8 * h + e) * TN + wn + j * 32 + (lane & 31)];
+                }
+            }
+    };
+    auto mfma16 = [&](const Frags8& f) {
+        u32x4 a1[FM], a2[FM], a3[FM], b1[NB][FN], b2[NB][FN], b3[NB][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) split3(f.a[i], a1[i], a2[i], a3[i]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) split3(f.b[b][j], b1[b][j], b2[b][j], b3[b][j]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    f32x16 c = acc[b][i][j];   // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a3[i]), as_bf16x8(b1[b][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b3[b][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a2[i]), as_bf16x8(b2[b][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a2[i]), as_bf16x8(b1[b][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b2[b][j]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b1[b][j]), c, 0, 0, 0);
+                    acc[b][i][j] = c;
+                }
+    };
     auto mfma_step = [&](const Frags& f, int s) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -627,6 +721,15 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     auto compute_stage = [&](const float* cur) {
         const float* la = cur;
         const float* lb = cur + A_SZ;
+        if constexpr (Cfg::SPLIT) {
+#pragma unroll
+            for (int s = 0; s < KB / 16; ++s) {
+                Frags8 f;
+                read_frags8(f, la, lb, s);
+                mfma16(f);
+            }
+            return;
+        }
 #ifndef DCV_NO_FRAG_DBUF
         // fragments double buffered in registers: group g+1 is read while group g feeds the MFMAs
         Frags f0, f1;
@@ -661,7 +764,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // full tile its EPASS * ENQ row segments are requested before the first stage is awaited, so they
     // stream in under the main loop instead of in a burst at the end while the matrix pipe idles
     // (short-K products are otherwise HBM-bound for the length of their epilogue and idle before it).
-    constexpr bool kSidePre = kStaged && Epi::kSide && (EPASS * ENQ <= 16) && ((Cfg::NBUF - 2) * 0 + EPASS * ENQ <= 32);
+    constexpr bool kSidePre = kStaged && Epi::kSide && (EPASS * ENQ <= 16) && !Cfg::SPLIT;   // SPLIT: the planes need the registers
     float4 side_pre[kSidePre ? EPASS * ENQ : 1];
     bool side_ready = false;
     // Two main loops in sequence.  The full stages of a workgroup whose tile is fully in range (the
@@ -684,7 +787,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         constexpr int GL = (A_MM ? MMajorStage<TM, KB, VEC, GATHER>::PER : KMajorStage<TM, KB, VEC, GATHER>::PER) +
                            NB * (B_MM ? MMajorStage<TN, KB, VEC, GATHER>::PER : KMajorStage<TN, KB, VEC, GATHER>::PER);  // DMA instructions per thread and stage
         static_assert((NBUF - 2) * GL <= 63, "vmcnt range");
-        static_assert(G % 2 == 0, "fragment double buffer parity");
+        static_assert(Cfg::SPLIT || G % 2 == 0, "fragment double buffer parity");
 #pragma unroll
         for (int s = 0; s < NBUF - 1; ++s)
             if (s < nst) glds_stage(k_begin + s * KB, s);
@@ -710,6 +813,39 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #endif
         DCV_STAMP_AT(1);
         DCV_STAMP_RT(5);
+        if constexpr (Cfg::SPLIT) {
+            // same ring, 16-deep steps: the last step of a stage is multiplied after the boundary work
+            constexpr int S = KB / 16;
+            Frags8 f0, f1;
+            read_frags8(f0, lds, lds + A_SZ, 0);
+            int cur_buf = 0;
+            for (int64_t st = 0; st < nst; ++st) {
+                const float* la = lds + cur_buf * STAGE;
+                const float* lb = la + A_SZ;
+                const int nxt_buf = cur_buf + 1 == NBUF ? 0 : cur_buf + 1;
+                if constexpr (S == 2) {
+                    read_frags8(f1, la, lb, 1);
+                    mfma16(f0);
+                }
+                vm_wait_younger<NBUF - 2, GL>(nst - 2 - st);
+#ifndef DCV_ABL_NOBARRIER
+                __syncthreads();
+#endif
+#ifndef DCV_ABL_NOLOAD
+                if (st + NBUF < nst) glds_stage(k_begin + (st + NBUF) * KB, cur_buf);
+#endif
+                if constexpr (S == 2) {
+                    read_frags8(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
+                    mfma16(f1);
+                } else {
+                    read_frags8(f1, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
+                    mfma16(f0);
+                    f0 = f1;
+                }
+                cur_buf = nxt_buf;
+            }
+            __syncthreads();   // last stage fully read before the buffers are reused
+        } else {
         Frags f0, f1;
         read_frags(f0, lds, lds + A_SZ, 0);
         int cur_buf = 0;
@@ -763,6 +899,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             cur_buf = nxt_buf;
         }
         __syncthreads();   // last stage fully read before the buffers are reused
+        }
     } else {
         DCV_STAMP_AT(1);
         DCV_STAMP_RT(5);

@@ -259,14 +259,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
     gemm_block<MODE, Cfg, NB, VEC, GATHER, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
 }
 
-#ifndef DCV_BIGCFG
-#define DCV_BIGCFG TileCfg<2, 2, 2, 2, 32>
+// Tile configurations, each in two arithmetic flavours (template argument S): the FP32-input MFMA
+// (S = false) and FP32-accurate split products on the BF16 matrix pipe (S = true, gemm.h: split3 / mfma16);
+// gemm_split() picks at launch time (dcv_set_gemm_mode / DCV_GEMM_MODE).
+template <bool S> using CfgBigT = TileCfg<2, 2, 2, 2, 32, 2, S>;      // 128 x 128
+template <bool S> using CfgHalfMT = TileCfg<2, 2, 1, 2, 32, 2, S>;    // 64 x 128: twice the workgroups when the row count is small
+template <bool S> using CfgNarrowNT = TileCfg<4, 1, 1, 1, 32, 2, S>;  // 128 x 32
+template <bool S> using CfgNarrowMT = TileCfg<1, 4, 1, 1, 32, 2, S>;  // 32 x 128
+template <bool S> using CfgCovT = TileCfg<2, 2, 2, 2, 16, 2, S>;      // 128 x 128, two B operands, 48 KiB LDS
+#ifdef DCV_BIGCFG
+using CfgBig = DCV_BIGCFG;   // diagnostic override (tools/gemm_bench)
+#else
+using CfgBig = CfgBigT<false>;
 #endif
-using CfgBig = DCV_BIGCFG;  // 128 x 128
-using CfgHalfM = TileCfg<2, 2, 1, 2, 32>;    // 64 x 128: twice the workgroups when the row count is small
-using CfgNarrowN = TileCfg<4, 1, 1, 1, 32>;  // 128 x 32
-using CfgNarrowM = TileCfg<1, 4, 1, 1, 32>;  // 32 x 128
-using CfgCov = TileCfg<2, 2, 2, 2, 16>;      // 128 x 128, two B operands, 48 KiB LDS
 
 template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
 static int launch_gemm_vec(const Operand& A, const Operand& B, int64_t lag2, const GemmDims& d, int64_t splits,
@@ -324,21 +329,37 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
 // Picks the tile shape from the output extents.  Row-parallel products (NT / NN) fall back to
 // shorter tiles when 128-row tiles would leave CUs without two resident workgroups (small per-GPU
 // batches of a multi-GPU run); TN products get their parallelism from the split count instead.
-template <int MODE, class Epi>
-static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
-                       const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
-    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowN, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
-    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+template <int MODE, bool S, class Epi>
+static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
+                            const Epi& epi, hipStream_t s, int* tiles_m_out) {
+#ifdef DCV_BIGCFG
+    using Big = CfgBig;
+#else
+    using Big = CfgBigT<S>;
+#endif
+    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
     if constexpr (MODE != kTN) {
         const int64_t want = 2 * (int64_t)num_cus();
         const int64_t tn = cdiv(N, 128);
         if (cdiv(M, 128) * tn < want) {
-            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return launch_gemm_cfg<MODE, CfgHalfM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
-            if (cdiv(M, 64) * tn < want / 2) return launch_gemm_cfg<MODE, CfgNarrowM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
-            return launch_gemm_cfg<MODE, CfgHalfM, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            if (cdiv(M, 64) * tn < want / 2) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
         }
     }
-    return launch_gemm_cfg<MODE, CfgBig, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+}
+
+template <int MODE, class Epi>
+static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
+                       const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
+#ifdef DCV_BIGCFG
+    return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out);
+#else
+    if (gemm_split()) return launch_gemm_mode<MODE, true, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out);
+    return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out);
+#endif
 }
 
 inline Operand make_operand(const float* p, int64_t ld, int64_t inner_extent, const RowMap& rows = RowMap{nullptr, 0, 0, 0},

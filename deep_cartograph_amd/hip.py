@@ -149,6 +149,17 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Cm
 
 
+# ------------------------------------------------------------------------------- arithmetic mode
+def set_gemm_mode(mode: str) -> None:
+    """'split' (default): FP32-accurate split products on the BF16 matrix pipe; 'native': FP32-input MFMA."""
+    lib = _lib.load()
+    check(lib.dcv_set_gemm_mode({"native": 0, "split": 1}[mode]), "dcv_set_gemm_mode")
+
+
+def get_gemm_mode() -> str:
+    return "split" if _lib.load().dcv_get_gemm_mode() == 1 else "native"
+
+
 # ------------------------------------------------------------------------------- k-means
 def kmeans_step(P: torch.Tensor, centers: torch.Tensor, labels: torch.Tensor, offset: Optional[torch.Tensor] = None,
                 want_mindist=False):

@@ -45,6 +45,18 @@ const char* dcv_last_error(void);
 /* Number of compute units and bytes of device memory of HIP device `device`. */
 int dcv_device_info(int device, int* n_cu, int64_t* hbm_bytes, char* name, size_t name_len);
 
+/* Arithmetic of every matrix product of the library (time-lagged covariances, MLP forward / backward):
+ *   DCV_GEMM_NATIVE_F32   v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate (157.3 TFLOP/s peak);
+ *   DCV_GEMM_SPLIT_BF16X6 each f32 operand split into three bf16 pieces (8 + 8 + 8 mantissa bits), six
+ *                         v_mfma_f32_32x32x16_bf16 products per block, f32 accumulate: the dropped cross terms
+ *                         are <= 2^-23 of a product, i.e. the accuracy of an f32 multiply (measured error vs
+ *                         float64 at or below the native path's), on the 16x faster BF16 matrix pipe.  Default.
+ * Process-wide; also settable with the environment variable DCV_GEMM_MODE=native|split before the first product. */
+#define DCV_GEMM_NATIVE_F32 0
+#define DCV_GEMM_SPLIT_BF16X6 1
+int dcv_set_gemm_mode(int mode);
+int dcv_get_gemm_mode(void);
+
 /* ---------------------------------------------------------------- column statistics (a1)
  * Replaces DataFrame.agg(['mean','std','min','max']) in CVCalculator.load_training_data,
  * cv_calculator.py:294-297.  One pass over X (n x F float32).  `out_d` receives 4*F

@@ -23,7 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, FP32-input MFMA (dense)
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, FP32-input MFMA (dense)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, BF16 MFMA (dense); the split arithmetic issues 6 bf16 MFMA flops per fp32 flop
 
 
 def parse():
@@ -46,6 +47,10 @@ def parse():
     p.add_argument("--alt-batch", type=int, default=8192,
                    help="also report (field 'secondary') the throughput at this global batch -- the size SURVEY.md 8d floated; 0 disables")
     p.add_argument("--alt-steps", type=int, default=300)
+    p.add_argument("--gemm-mode", choices=["split", "native"], default="split",
+                   help="arithmetic of the MLP products: 'split' = FP32-accurate split products on the BF16 matrix pipe "
+                        "(library default), 'native' = FP32-input MFMA; the other mode is timed too (field 'other_gemm_mode')")
+    p.add_argument("--other-mode-steps", type=int, default=40)
     return p.parse_args()
 
 
@@ -146,6 +151,7 @@ def main():
     hip.normalize(X, mean_t, range_t, out=X)   # in place: Xn
     Xn = X
 
+    hip.set_gemm_mode(a.gemm_mode)
     linears = init_linears(dims, 43)
     eng = hip.Mlp("deep_tica", dims, acts, max_batch=lb, lag=lag, tica_reg=1e-6, lr=a.lr)
     eng.set_linears(linears)
@@ -198,6 +204,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- the same training steps in the other arithmetic mode (the mode is a launch-time switch of the library)
+    other = "native" if a.gemm_mode == "split" else "split"
+    other_res = None
+    if a.other_mode_steps > 0:
+        hip.set_gemm_mode(other)
+        for i in range(5):
+            train_step(i)
+        barrier()
+        t0o = time.perf_counter()
+        for i in range(a.other_mode_steps):
+            train_step(i)
+        barrier()
+        elo = time.perf_counter() - t0o
+        hip.set_gemm_mode(a.gemm_mode)
+        if dist is not None:
+            t = torch.tensor([elo], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elo = float(t.item())
+        other_res = {"gemm_mode": other, "value": a.other_mode_steps * a.batch / elo, "unit": "frames/s",
+                     "ms_per_step": elo / a.other_mode_steps * 1e3, "steps": a.other_mode_steps,
+                     "note": "training steps only (no validation pass), same engine state, arithmetic switched at launch time"}
+
     if rank == 0:
         R = lb + lag   # contiguous batches: the network runs once on the batch + lag rows both halves share
         flops = {}
@@ -213,6 +241,17 @@ def main():
             tj = json.load(open(tpath))
             if tj.get("rows_per_launch") == R:
                 traffic = tj["kernels"].get(f"layer{dl}.{dk}", {}).get("hbm_bytes_per_launch")
+        if a.gemm_mode == "split":
+            # every fp32 flop is 6 bf16 MFMA flops: the ceiling of this arithmetic is the BF16 pipe's dense peak / 6
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+            kname = f"layer{dl}.{dk} (gemm_kernel, 6 x v_mfma_f32_32x32x16_bf16 per FP32-accurate 32x32x16 block)"
+            peak_note = ("algorithmic fp32 flop / time against the BF16 dense MFMA peak (2500 TFLOP/s) / 6 products per block; "
+                         f"the same rate is {achieved / PEAK_F32_MFMA_TFLOPS:.2f} x the FP32-input MFMA peak of {PEAK_F32_MFMA_TFLOPS} TFLOP/s "
+                         "(which bounds --gemm-mode native, timed in 'other_gemm_mode')")
+        else:
+            peak = PEAK_F32_MFMA_TFLOPS
+            kname = f"layer{dl}.{dk} (gemm_kernel, FP32 MFMA 32x32x2)"
+            peak_note = "algorithmic fp32 flop / time against the FP32-input MFMA dense peak"
         sw = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
         losses = log[:, 0]
         out = {
@@ -227,6 +266,10 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
+            "arithmetic": ("FP32-input MFMA (exact f32 products, f32 accumulate)" if a.gemm_mode == "native" else
+                           "f32 operands split into 3 bf16 pieces, 6 bf16 MFMA products per block, f32 accumulate: f32-accurate "
+                           "(error vs float64 at or below the FP32-input MFMA path, tests/test_kernels_gpu.py); covariances / linear CVs "
+                           "always use the FP32-input MFMA"),
             "data": "synthetic",
             "config": {
                 "workload": f"Deep-TICA fit, {a.frames}x{F} f32 synthetic AR(1) features (SURVEY 8d, C4), MLP {'-'.join(map(str, dims))}, "
@@ -239,12 +282,16 @@ def main():
             "loss_first": float(losses[0]) if len(losses) else None,
             "loss_last_train": float(losses[-1]) if len(losses) else None,
             "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
-                "kernel": f"layer{dl}.{dk} (gemm_kernel, FP32 MFMA 32x32x2)", "flop_per_launch": dfl, "avg_ms": dms,
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic,
+                "kernel": kname, "flop_per_launch": dfl, "avg_ms": dms,
                 "all_kernels_ms": {f"layer{l}.{k}": v[1] for (l, k), v in sorted(flops.items())},
+                "note": peak_note,
             },
         }
+        out["config"]["gemm_mode"] = a.gemm_mode
+        if other_res is not None:
+            out["other_gemm_mode"] = other_res
     eng.close()
     # ---- secondary: the same fit at the small global batch of SURVEY 8d (launch-latency bound; every rank runs it)
     alt = None

@@ -105,6 +105,41 @@ def test_gemm_random_fp32(mode):
     assert np.all(np.abs(out.cpu().numpy() - ref) <= bound + 1e-6)
 
 
+def test_gemm_modes_split_vs_native():
+    """The two arithmetic flavours of the product engine (dcv_set_gemm_mode): FP32-input MFMA and FP32-accurate split
+    products on the BF16 pipe.  Both meet the fp32 error bound against float64 on zero-mean data; on a long same-sign
+    accumulation (K = 8192) the BF16 pipe's truncating accumulator shows its bias -- bounded here at 4e-5 relative,
+    which is why the covariance kernels never use it -- while the native path stays unbiased."""
+    from deep_cartograph_amd import hip
+
+    start = hip.get_gemm_mode()
+    try:
+        rng = np.random.Generator(np.random.PCG64(8))
+        A = rng.standard_normal((256, 512)).astype(np.float32)
+        B = rng.standard_normal((192, 512)).astype(np.float32)
+        ref = A.astype(np.float64) @ B.astype(np.float64).T
+        bound = 4e-7 * (np.abs(A).astype(np.float64) @ np.abs(B).astype(np.float64).T)
+        outs = {}
+        for mode in ("native", "split"):
+            hip.set_gemm_mode(mode)
+            assert hip.get_gemm_mode() == mode
+            outs[mode] = hip.gemm("nt", dev(A), dev(B)).cpu().numpy()
+            assert np.all(np.abs(outs[mode] - ref) <= bound + 1e-6), mode
+        assert not np.array_equal(outs["native"], outs["split"])       # the switch does switch
+        Ap = (rng.random((8192, 128)) + 0.1).astype(np.float32)        # K = 8192 rows of positive numbers (TN form)
+        Bp = (rng.random((8192, 128)) + 0.1).astype(np.float32)
+        refp = Ap.astype(np.float64).T @ Bp.astype(np.float64)
+        rel = {}
+        for mode in ("native", "split"):
+            hip.set_gemm_mode(mode)
+            got = hip.gemm("tn", dev(Ap), dev(Bp)).cpu().numpy()
+            rel[mode] = (got - refp) / refp
+        assert np.max(np.abs(rel["native"])) < 2e-5 and abs(rel["native"].mean()) < 2e-6
+        assert np.max(np.abs(rel["split"])) < 4e-5
+    finally:
+        hip.set_gemm_mode(start)
+
+
 @pytest.mark.parametrize("n,F,lag,shift", [(5000, 64, 3, False), (3000, 54, 1, True), (40000, 256, 10, False),
                                            (20000, 128, 0, True), (1500, 300, 7, True), (40, 8, 39, False)])
 def test_lagged_cov_vs_float64(n, F, lag, shift):

@@ -666,29 +666,36 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 }
             }
     };
-    auto mfma16 = [&](const Frags8& f) {
+    struct Planes {   // the three bf16 pieces of a Frags8
         u32x4 a1[FM], a2[FM], a3[FM], b1[NB][FN], b2[NB][FN], b3[NB][FN];
+    };
+    auto split_frags = [&](const Frags8& f, Planes& p) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) split3(f.a[i], a1[i], a2[i], a3[i]);
-#pragma unroll
-        for (int b = 0; b < NB; ++b)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) split3(f.b[b][j], b1[b][j], b2[b][j], b3[b][j]);
+        for (int i = 0; i < FM; ++i) split3(f.a[i], p.a1[i], p.a2[i], p.a3[i]);
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    f32x16 c = acc[b][i][j];   // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a3[i]), as_bf16x8(b1[b][j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b3[b][j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a2[i]), as_bf16x8(b2[b][j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a2[i]), as_bf16x8(b1[b][j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b2[b][j]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(a1[i]), as_bf16x8(b1[b][j]), c, 0, 0, 0);
-                    acc[b][i][j] = c;
-                }
+            for (int j = 0; j < FN; ++j) split3(f.b[b][j], p.b1[b][j], p.b2[b][j], p.b3[b][j]);
+    };
+    // six products per accumulator tile, small cross terms first; `between(k)` runs after the k-th product type
+    // (k = 0..5) -- the stage boundary hangs its scalar DMA issue there, under MFMAs already in flight
+    auto mfma_planes = [&](const Planes& p, auto&& between) {
+#define DCV_SPLIT_PRODUCT(PA, PB, K)                                                                                           \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b) _Pragma("unroll") for (int i = 0; i < FM; ++i) _Pragma("unroll") for (int j = 0; j < FN; ++j) \
+        acc[b][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(p.PA[i]), as_bf16x8(p.PB[b][j]), acc[b][i][j], 0, 0, 0); \
+    between(K);
+        DCV_SPLIT_PRODUCT(a3, b1, 0)
+        DCV_SPLIT_PRODUCT(a1, b3, 1)
+        DCV_SPLIT_PRODUCT(a2, b2, 2)
+        DCV_SPLIT_PRODUCT(a2, b1, 3)
+        DCV_SPLIT_PRODUCT(a1, b2, 4)
+        DCV_SPLIT_PRODUCT(a1, b1, 5)
+#undef DCV_SPLIT_PRODUCT
+    };
+    auto mfma16 = [&](const Frags8& f) {
+        Planes p;
+        split_frags(f, p);
+        mfma_planes(p, [](int) {});
     };
     auto mfma_step = [&](const Frags& f, int s) {
 #pragma unroll
@@ -826,18 +833,34 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 if constexpr (S == 2) {
                     read_frags8(f1, la, lb, 1);
                     mfma16(f0);
-                }
-                vm_wait_younger<NBUF - 2, GL>(nst - 2 - st);
+                    // the last step's operands are split before the boundary; behind the barrier only its MFMAs
+                    // remain, with the scalar DMA issue of stage st + NBUF and the next fragment reads between them
+                    Planes pl;
+                    split_frags(f1, pl);
+                    vm_wait_younger<NBUF - 2, GL>(nst - 2 - st);
 #ifndef DCV_ABL_NOBARRIER
-                __syncthreads();
+                    __syncthreads();
+#endif
+                    read_frags8(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
+                    const bool more = st + NBUF < nst;
+                    const int64_t k_next = k_begin + (st + NBUF) * KB;
+                    mfma_planes(pl, [&](int k) {
+#ifndef DCV_ABL_NOLOAD
+                        if (k == 0 || k == 2) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (more) glds_stage(k_next, cur_buf, k == 0 ? 1 : 2);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#endif
+                    });
+                } else {
+                    vm_wait_younger<NBUF - 2, GL>(nst - 2 - st);
+#ifndef DCV_ABL_NOBARRIER
+                    __syncthreads();
 #endif
 #ifndef DCV_ABL_NOLOAD
-                if (st + NBUF < nst) glds_stage(k_begin + (st + NBUF) * KB, cur_buf);
+                    if (st + NBUF < nst) glds_stage(k_begin + (st + NBUF) * KB, cur_buf);
 #endif
-                if constexpr (S == 2) {
-                    read_frags8(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
-                    mfma16(f1);
-                } else {
                     read_frags8(f1, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
                     mfma16(f0);
                     f0 = f1;

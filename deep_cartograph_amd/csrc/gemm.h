@@ -448,6 +448,20 @@ __device__ __forceinline__ float4 load_quad(const float* p, int nvalid, bool vec
     return v;
 }
 
+// Sign mask of an activation tile, in the thread layout of the staged epilogue: for row segment q of a tile
+// (the thread's q-th 4-column piece) wave w stores four 64-bit ballots, one per column of the piece, bit = lane:
+//   word (((tile * NQT + q) * 4 + w) * 4 + c).
+// The dgrad of a ReLU-family layer needs only sign(H) (1 bit per element instead of 32), and the dgrad epilogue
+// of the same tile shape reads its bits back with the same indexing.
+template <int N>
+__device__ __forceinline__ void store_sign_mask(unsigned long long* mask, const float4 (&v)[N], int64_t seg0, int wave, int lane) {
+#pragma unroll
+    for (int q = 0; q < N; ++q) {
+        const unsigned long long bx = __ballot(v[q].x > 0.f), by = __ballot(v[q].y > 0.f);
+        const unsigned long long bz = __ballot(v[q].z > 0.f), bw = __ballot(v[q].w > 0.f);
+        if (lane < 4) mask[((seg0 + q) * 4 + wave) * 4 + lane] = lane == 0 ? bx : (lane == 1 ? by : (lane == 2 ? bz : bw));
+    }
+}
 // s_waitcnt vmcnt(N) through asm: the LDS-DMA instructions it counts are asm too (see glds16)
 template <int N>
 __device__ __forceinline__ void vm_wait() {
@@ -802,6 +816,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         if constexpr (kSidePre) {
             static_assert((NBUF - 2) * GL + EPASS * ENQ <= 63, "vmcnt range");
             side_ready = epi.vec && (m0 + TM <= d.M) && (n0 + TN <= d.N);
+            if constexpr (Epi::kMaskIn) side_ready = side_ready && epi.mask == nullptr;
             if (side_ready) {
                 const int ec4 = t % EC4, er0 = t / EC4;
 #pragma unroll
@@ -1016,9 +1031,15 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
             for (int qc = 0; qc < NQ; qc += EQ) {
                 float4 v[EQ], side[Epi::kSide ? EQ : 1];
+                bool masked = false;   // workgroup-uniform: the activation derivative comes from a sign mask
+                if constexpr (Epi::kMaskIn) masked = epi.mask != nullptr;
                 if constexpr (Epi::kSide) {
 #pragma unroll
                     for (int q = 0; q < EQ; ++q) {
+                        if (masked) {
+                            side[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            continue;
+                        }
                         const int64_t row = mbase + r0 + (qc + q) * RPP;
                         if constexpr (kSidePre) {
                             if (side_ready) {   // requested before the main loop (row segment ep * NQ + qc + q of this thread)
@@ -1032,7 +1053,16 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 }
 #pragma unroll
                 for (int q = 0; q < EQ; ++q) v[q] = *reinterpret_cast<const float4*>(tile + (r0 + (qc + q) * RPP) * TN + c4 * 4);
-                epi.template transform<EQ>(v, side, cc);
+                const int64_t seg0 = ((int64_t)tile_m * d.tiles_n + tile_n) * (EPASS * NQ) + ep * NQ + qc;   // first row segment of this chunk
+                if constexpr (Epi::kMaskIn) {
+                    if (masked) epi.template apply_mask<EQ>(v, seg0, wave, lane);
+                    else epi.template transform<EQ>(v, side, cc);
+                } else {
+                    epi.template transform<EQ>(v, side, cc);
+                }
+                if constexpr (Epi::kMaskOut) {
+                    if (epi.mask != nullptr) store_sign_mask<EQ>(epi.mask, v, seg0, wave, lane);
+                }
                 if constexpr (Epi::kHead) epi.template head<EQ, C4>(v, mbase + r0 + qc * RPP, RPP, col, nvalid, d.M, lane);
                 if (fast) {
 #pragma unroll

@@ -47,6 +47,8 @@ struct EpiStore {  // C = acc
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = false;
+    static constexpr bool kMaskOut = false;
+    static constexpr bool kMaskIn = false;
     float* C;
     int64_t ldc;
     bool vec;
@@ -60,11 +62,14 @@ struct EpiBiasAct {  // H = act(acc + bias[col])
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = false;
+    static constexpr bool kMaskOut = true;
+    static constexpr bool kMaskIn = false;
     float* C;
     int64_t ldc;
     const float* bias;
     int act;
     bool vec;
+    unsigned long long* mask = nullptr;   // optional sign mask of H (ReLU family), see store_sign_mask
     __device__ __forceinline__ float4 colconst(int64_t c, int nvalid) const {
         return bias ? load_quad(bias + c, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -121,6 +126,8 @@ struct EpiBiasActHead {
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = true;
+    static constexpr bool kMaskOut = false;
+    static constexpr bool kMaskIn = false;
     float* C;
     int64_t ldc;
     const float* bias;
@@ -175,6 +182,8 @@ struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> b
     static constexpr bool kColSum = true;
     static constexpr bool kSide = true;
     static constexpr bool kHead = false;
+    static constexpr bool kMaskOut = false;
+    static constexpr bool kMaskIn = true;
     float* C;
     int64_t ldc;
     const float* H;
@@ -183,6 +192,19 @@ struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> b
     float* bpart;  // [tiles_m][n]
     int64_t n;
     bool vec;
+    const unsigned long long* mask = nullptr;   // sign mask of H written by the forward of the same tile shape: H is not read
+    float slope = 0.f;                          // derivative where H <= 0 (0.01 leaky ReLU, 0 ReLU)
+    template <int N>
+    __device__ __forceinline__ void apply_mask(float4 (&v)[N], int64_t seg0, int wave, int lane) const {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const unsigned long long* w = mask + ((seg0 + q) * 4 + wave) * 4;
+            if (!((w[0] >> lane) & 1ull)) v[q].x *= slope;
+            if (!((w[1] >> lane) & 1ull)) v[q].y *= slope;
+            if (!((w[2] >> lane) & 1ull)) v[q].z *= slope;
+            if (!((w[3] >> lane) & 1ull)) v[q].w *= slope;
+        }
+    }
     __device__ __forceinline__ float4 colconst(int64_t, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ const float* side_ptr(int64_t r, int64_t c) const { return H + r * ldh + c; }
     template <int N>
@@ -202,6 +224,8 @@ struct EpiSlab {  // split-K partials: slab[z][which][M][N]
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = false;
+    static constexpr bool kMaskOut = false;
+    static constexpr bool kMaskIn = false;
     float* slab;
     int64_t M, N;
     int nb;

@@ -29,6 +29,8 @@ struct LayerPlan {
     int64_t max_splits;
     float* slab;               // [max_splits][out][in]
     float* bpart;              // [bias_blocks_cap][out]
+    unsigned long long* mask;  // sign mask of H in the forward epilogue's thread layout (ReLU family), or null
+    int64_t mask_rows;         // row count of the training forward that wrote it (-1: stale)
 };
 
 }  // namespace dcv
@@ -781,7 +783,7 @@ static void mlp_free(dcv_mlp* m) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
-    for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); }
+    for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); }
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     delete m;
 }
@@ -856,6 +858,10 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         rc = dmalloc(&p.H, (size_t)m->rows_cap * p.ldh);
         if (rc == DCV_OK) rc = dmalloc(&p.slab, (size_t)p.max_splits * p.in * p.out);
         if (rc == DCV_OK) rc = dmalloc(&p.bpart, (size_t)cdiv(m->rows_cap, 32) * p.out);  // row tiles of the dgrad epilogue can be as short as 32
+        p.mask = nullptr;
+        p.mask_rows = -1;
+        if (rc == DCV_OK && l + 1 < L && (p.act == DCV_ACT_RELU || p.act == DCV_ACT_LEAKY_RELU))   // one bit per element, whole tiles
+            rc = dmalloc(&p.mask, (size_t)((m->rows_cap + 128) * (int64_t)(p.out + 128)) / 64 + 64);
     }
     m->n_params = off;
     m->ld_dz = align_up((size_t)maxdim, 4);
@@ -993,6 +999,10 @@ extern "C" int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, 
     return DCV_OK;
 }
 
+static bool act_mask_enabled() {
+    static const bool off = [] { const char* e = getenv("DCV_NO_ACT_MASK"); return e && e[0] == '1'; }();
+    return !off;
+}
 // layer l + 1 can ride in the epilogue of layer l: it is narrow and layer l's output fits one column tile
 static bool next_layer_fusable(const dcv_mlp* m, int l) {
     static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
@@ -1001,9 +1011,11 @@ static bool next_layer_fusable(const dcv_mlp* m, int l) {
 }
 
 // forward through layers [0, n_run) for `rows` logical rows
-static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& rows_map, int64_t rows, int n_run, hipStream_t s) {
+static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& rows_map, int64_t rows, int n_run, hipStream_t s,
+                       bool for_backward = false) {
     for (int l = 0; l < n_run; ++l) {
         LayerPlan& p = m->layers[l];
+        p.mask_rows = -1;
         Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
         Operand B = make_operand(m->params + p.w_off, p.in, p.in);
         if (l + 1 < n_run && next_layer_fusable(m, l)) {
@@ -1027,6 +1039,10 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             continue;
         }
         EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act, quad_ok(p.H, p.ldh) && quad_ok(m->params + p.b_off, 4)};
+        if (for_backward && p.mask && act_mask_enabled()) {   // the dgrad of the next layer reads sign(H) instead of H
+            epi.mask = p.mask;
+            p.mask_rows = rows;
+        }
         prof_mark(m, l, 0, 0, s);
         int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s);
         if (rc) return rc;
@@ -1043,7 +1059,7 @@ extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const 
     hipStream_t s = as_stream(stream);
     const RowMap rm = batch_rows(m, idx_d, row0, batch);
     const int64_t R = rows_of(m, idx_d, batch);
-    int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s);
+    int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s, true);
     if (rc) return rc;
     const LayerPlan& last = m->layers[m->L - 1];
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
@@ -1180,6 +1196,10 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
             Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
             Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
             EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
+            if (q.mask && q.mask_rows == R) {   // written by this step's forward with the same (rows, width) => same tiling
+                eg.mask = q.mask;
+                eg.slope = q.act == DCV_ACT_LEAKY_RELU ? 0.01f : 0.f;
+            }
             prof_mark(m, l, 2, 0, s);
             rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks);
             if (rc) return rc;

@@ -54,6 +54,7 @@ struct dcv_mlp {
     int spart_blocks;
     double* log;
     int* log_count;
+    unsigned* ticket;          // block counter of the single-launch statistics reduction (zero between launches)
     int log_cap, log_width;
     float* feat_range;         // AE
     float *ident, *zeros_d, *ones_d;  // helpers for inference
@@ -215,9 +216,11 @@ __global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict
 constexpr int kFastStatRows = 2048;
 template <int D>
 __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __restrict__ F, int64_t ld, int B, int lag_off,
-                                                              double* __restrict__ part) {
+                                                              double* __restrict__ part, unsigned* __restrict__ ticket,
+                                                              double* __restrict__ out) {
     constexpr int W = 2 * D + 2 * D * D;
     __shared__ double red[4][W];
+    __shared__ unsigned s_last;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double acc[W];
 #pragma unroll
@@ -250,8 +253,23 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
     }
     __syncthreads();
     if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    // the block that finishes last adds the partials up in block order (no second launch; same sums whichever
+    // block it is)
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        __threadfence();
+        if (t < W) {
+            double s = 0.0;
+            for (unsigned b = 0; b < gridDim.x; ++b) s += part[(int64_t)b * W + t];
+            out[t] = s;
+        }
+        if (t == 0) *ticket = 0u;
+    }
 }
-typedef void (*tica_stats_fn_t)(const float*, int64_t, int, int, double*);
+typedef void (*tica_stats_fn_t)(const float*, int64_t, int, int, double*, unsigned*, double*);
 static tica_stats_fn_t tica_stats_rows_fn(int d) {
     switch (d) {
         case 1: return tica_stats_rows_kernel<1>;
@@ -782,7 +800,7 @@ static void mlp_free(dcv_mlp* m) {
     if (!m) return;
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
-    f(m->spart); f(m->log); f(m->log_count); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
+    f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
     for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); }
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     delete m;
@@ -880,6 +898,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     if (rc == DCV_OK) rc = dmalloc(&m->gradp, (size_t)(2 * kMaxTicaDim + 2 * kMaxTicaDim * kMaxTicaDim));
     if (rc == DCV_OK) rc = dmalloc(&m->spart, (size_t)m->spart_blocks * m->stats_len);
     if (rc == DCV_OK) rc = dmalloc(&m->log_count, 1);
+    if (rc == DCV_OK) rc = dmalloc(&m->ticket, 1);
     if (rc == DCV_OK) rc = dmalloc(&m->feat_range, (size_t)desc->dims[0]);
     if (rc == DCV_OK) rc = dmalloc(&m->ident, (size_t)dl * dl);
     if (rc == DCV_OK) rc = dmalloc(&m->zeros_d, (size_t)dl);
@@ -897,6 +916,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     if (e == hipSuccess) e = hipMemset(m->adam_m, 0, m->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMemset(m->adam_v, 0, m->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMemset(m->log_count, 0, sizeof(int));
+    if (e == hipSuccess) e = hipMemset(m->ticket, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(m->zeros_d, 0, dl * sizeof(float));
     if (e == hipSuccess) e = hipMemset(m->ident, 0, (size_t)dl * dl * sizeof(float));
     if (e == hipSuccess) {
@@ -1066,7 +1086,11 @@ extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const 
         int nb;
         if (tica_stats_fn_t fast = tica_stats_rows_fn(m->d_out)) {
             nb = (int)cdiv(batch, kFastStatRows);
-            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, (const float*)last.H, last.ldh, (int)batch, lag_offset(m, idx_d, batch), m->spart);
+            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, (const float*)last.H, last.ldh, (int)batch, lag_offset(m, idx_d, batch), m->spart,
+                               m->ticket, m->stats);
+            DCV_CHECK_LAUNCH();
+            m->last_batch = batch;
+            return DCV_OK;
         } else {
             nb = (int)cdiv(batch, kStatBlockRows);
             hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, last.H,

@@ -685,7 +685,18 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     };
     auto split_frags = [&](const Frags8& f, Planes& p) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i) split3(f.a[i], p.a1[i], p.a2[i], p.a3[i]);
+        for (int i = 0; i < FM; ++i) {
+#ifdef DCV_ABL_NOSPLIT_A   // diagnostic: what a pre-split A operand would save (wrong results)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p.a1[i][e] = __builtin_amdgcn_perm(__float_as_uint(f.a[i][2 * e + 1]), __float_as_uint(f.a[i][2 * e]), 0x07060302);
+                p.a2[i][e] = p.a1[i][e];
+                p.a3[i][e] = p.a1[i][e];
+            }
+#else
+            split3(f.a[i], p.a1[i], p.a2[i], p.a3[i]);
+#endif
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll

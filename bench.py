@@ -212,11 +212,13 @@ def main():
         for i in range(5):
             train_step(i)
         barrier()
+        eng.profile_begin(a.other_mode_steps, 1)
         t0o = time.perf_counter()
         for i in range(a.other_mode_steps):
             train_step(i)
         barrier()
         elo = time.perf_counter() - t0o
+        prof_o = eng.profile_end()
         hip.set_gemm_mode(a.gemm_mode)
         if dist is not None:
             t = torch.tensor([elo], dtype=torch.float64, device=dev)
@@ -225,6 +227,13 @@ def main():
         other_res = {"gemm_mode": other, "value": a.other_mode_steps * a.batch / elo, "unit": "frames/s",
                      "ms_per_step": elo / a.other_mode_steps * 1e3, "steps": a.other_mode_steps,
                      "note": "training steps only (no validation pass), same engine state, arithmetic switched at launch time"}
+        if prof_o:   # the same roofline line for the other arithmetic: slower layer-0 product against that arithmetic's ceiling
+            (ol_, ok_), (oms, ocnt) = max(prof_o.items(), key=lambda kv: kv[1][0] / kv[1][1])
+            ofl = 2.0 * (lb + lag) * dims[ol_] * dims[ol_ + 1]
+            oach = ofl / (oms / ocnt * 1e-3) / 1e12
+            opeak = PEAK_F32_MFMA_TFLOPS if other == "native" else PEAK_BF16_MFMA_TFLOPS / 6.0
+            other_res["roofline"] = {"bound": "mfma", "kernel": f"layer{ol_}.{ok_}", "achieved": oach, "peak": opeak, "unit": "TFLOP/s",
+                                     "frac": oach / opeak, "avg_ms": oms / ocnt}
 
     if rank == 0:
         R = lb + lag   # contiguous batches: the network runs once on the batch + lag rows both halves share

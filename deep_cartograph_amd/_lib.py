@@ -75,6 +75,9 @@ SIGNATURES = {
     "dcv_mlp_read_log": (C.c_int, [_P, _P, _I32, C.POINTER(_I32), _P]),
     "dcv_mlp_profile_begin": (C.c_int, [_P, _I32, _I32]),
     "dcv_mlp_profile_end": (C.c_int, [_P, _P, _P]),
+    "dcv_mlp_profile_pause": (C.c_int, [_P, _I32]),
+    "dcv_mlp_graph_launches": (_I64, [_P]),
+    "dcv_mlp_set_graph": (C.c_int, [_P, _I32]),
     "dcv_mlp_infer": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P]),
     "dcv_mlp_input_sensitivity_workspace": (_SZ, [_P, _I64]),
     "dcv_mlp_input_sensitivity": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),

@@ -55,6 +55,12 @@ struct dcv_mlp {
     double* log;
     int* log_count;
     unsigned* ticket;          // block counter of the single-launch statistics reduction (zero between launches)
+    hipGraphExec_t gexec[4];   // instantiated step graphs (train step, forward, backward, eval step) or null
+    bool gwarm[4];             // the slot ran once outside capture (lazy module loading, first-use attributes)
+    bool graph_on;             // step graphs requested (dcv_mlp_set_graph; default from DCV_GRAPH=1)
+    bool graph_off;            // graph instantiation failed once: plain launches from then on
+    int64_t graph_launches;    // steps / half-steps that went out as one graph launch
+    bool prof_paused;          // profiling armed but skipped for the current calls (dcv_mlp_profile_pause)
     int log_cap, log_width;
     float* feat_range;         // AE
     float *ident, *zeros_d, *ones_d;  // helpers for inference
@@ -730,7 +736,7 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
 }
 
 static inline bool prof_on(const dcv_mlp* m, int layer) {
-    return m->prof_level > 0 && m->prof_step < m->prof_cap && (m->prof_level > 1 || layer == 0);
+    return m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap && (m->prof_level > 1 || layer == 0);
 }
 static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStream_t s) {
     if (!prof_on(m, layer)) return;
@@ -803,6 +809,7 @@ static void mlp_free(dcv_mlp* m) {
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
     for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); }
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 4; ++i) if (m->gexec[i]) (void)hipGraphExecDestroy(m->gexec[i]);
     delete m;
 }
 
@@ -819,6 +826,10 @@ static int dmalloc(T** p, size_t count) {
 
 }  // namespace dcv
 
+static bool graph_enabled() {
+    static const bool on = [] { const char* e = getenv("DCV_GRAPH"); return e && e[0] == '1'; }();
+    return on;
+}
 // =================================================================== C-ABI
 extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     DCV_REQUIRE(desc && out, "dcv_mlp_create: null argument");
@@ -849,6 +860,11 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->adam_t = 0;
     m->last_batch = 0;
     m->prof_level = m->prof_cap = m->prof_step = 0;
+    for (int i = 0; i < 4; ++i) { m->gexec[i] = nullptr; m->gwarm[i] = false; }
+    m->graph_on = graph_enabled();
+    m->graph_off = false;
+    m->graph_launches = 0;
+    m->prof_paused = false;
     m->layers.resize(L);
     int64_t off = 0;
     int maxdim = 0;
@@ -1071,8 +1087,61 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
     return DCV_OK;
 }
 
-extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
-                               void* stream) {
+// Optional (DCV_GRAPH=1; off by default): the launch sequence of a step is captured into a hipGraph each call and the
+// instantiated graph of the slot is UPDATED in place (same topology, new kernel arguments: batch offset, Adam bias
+// corrections), then launched once.  Needs a capturing-capable (non-null) stream; anything else -- null stream,
+// profiling on, first call of a slot, an update the runtime refuses -- takes the plain launches.  Measured on
+// MI355X / ROCm 7.2 it buys nothing: the 27 us of gaps per step stay (2.909 vs 2.910 ms at the bench size, 0.454 vs
+// 0.449 ms at one eighth of it, and the per-call capture costs the 8192-pair step 3 %), so plain launches are the
+// default and the path is kept as a tested option (tests/test_mlp_gpu.py::test_graphed_steps_match_plain_launches).
+template <class F>
+static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
+    if (!m->graph_on || m->graph_off || s == nullptr || (m->prof_level > 0 && !m->prof_paused) || !m->gwarm[slot]) {
+        m->gwarm[slot] = true;
+        return body();
+    }
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        return body();
+    }
+    const int64_t adam_t0 = m->adam_t;   // the only host state a replay of body() must not advance twice
+    const int rc = body();
+    hipGraph_t g = nullptr;
+    const hipError_t ec = hipStreamEndCapture(s, &g);
+    if (rc != DCV_OK || ec != hipSuccess || g == nullptr) {
+        if (g) (void)hipGraphDestroy(g);
+        (void)hipGetLastError();
+        if (rc != DCV_OK) return rc;
+        m->gwarm[slot] = false;   // capture failed: run this call (and relearn) without it
+        m->adam_t = adam_t0;
+        return body();
+    }
+    if (m->gexec[slot]) {
+        hipGraphNode_t err_node = nullptr;
+        hipGraphExecUpdateResult res = hipGraphExecUpdateSuccess;
+        if (hipGraphExecUpdate(m->gexec[slot], g, &err_node, &res) != hipSuccess || res != hipGraphExecUpdateSuccess) {
+            (void)hipGetLastError();
+            (void)hipGraphExecDestroy(m->gexec[slot]);
+            m->gexec[slot] = nullptr;
+        }
+    }
+    if (!m->gexec[slot] && hipGraphInstantiate(&m->gexec[slot], g, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        m->gexec[slot] = nullptr;
+    }
+    (void)hipGraphDestroy(g);
+    if (!m->gexec[slot]) {   // nothing was launched yet: replay as plain launches and stop trying on this slot
+        m->graph_off = true;
+        m->adam_t = adam_t0;
+        return body();
+    }
+    DCV_CHECK_HIP(hipGraphLaunch(m->gexec[slot], s));
+    m->graph_launches += 1;
+    return DCV_OK;
+}
+
+static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                        void* stream) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_forward: null argument");
     DCV_REQUIRE(batch >= 1 && batch <= m->desc.max_batch, "dcv_mlp_forward: batch=%d exceeds max_batch=%d", batch, m->desc.max_batch);
     DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_forward: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
@@ -1110,8 +1179,8 @@ extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const 
     return DCV_OK;
 }
 
-extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
-                                int64_t global_batch, int32_t train, void* stream) {
+static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                         int64_t global_batch, int32_t train, void* stream) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_backward: null argument");
     if (m->last_batch != batch) {
         set_error("dcv_mlp_backward: batch=%d does not match the preceding forward (%d)", batch, m->last_batch);
@@ -1235,7 +1304,7 @@ extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const
     }
     hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f);
     DCV_CHECK_LAUNCH();
-    if (m->prof_level > 0 && m->prof_step < m->prof_cap) m->prof_step += 1;
+    if (m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
     return DCV_OK;
 }
 
@@ -1250,6 +1319,12 @@ extern "C" int dcv_mlp_profile_begin(dcv_mlp* m, int32_t max_steps, int32_t leve
     m->prof_cap = max_steps;
     m->prof_step = 0;
     m->prof_level = level;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_profile_pause(dcv_mlp* m, int32_t paused) {
+    DCV_REQUIRE(m, "dcv_mlp_profile_pause: null");
+    m->prof_paused = paused != 0;
     return DCV_OK;
 }
 
@@ -1277,7 +1352,7 @@ extern "C" int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h) 
     return DCV_OK;
 }
 
-extern "C" int dcv_mlp_apply(dcv_mlp* m, void* stream) {
+static int apply_impl(dcv_mlp* m, void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_apply: null");
     hipStream_t s = as_stream(stream);
     m->adam_t += 1;
@@ -1292,20 +1367,47 @@ extern "C" int dcv_mlp_apply(dcv_mlp* m, void* stream) {
     return DCV_OK;
 }
 
+extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                               void* stream) {
+    DCV_REQUIRE(m, "dcv_mlp_forward: null");
+    return run_graphed(m, 1, as_stream(stream), [&] { return forward_impl(m, Xn_d, ld, idx_d, row0, batch, stream); });
+}
+
+extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                                int64_t global_batch, int32_t train, void* stream) {
+    DCV_REQUIRE(m, "dcv_mlp_backward: null");
+    if (!train) return backward_impl(m, Xn_d, ld, idx_d, row0, batch, global_batch, train, stream);   // one tiny launch
+    return run_graphed(m, 2, as_stream(stream), [&] { return backward_impl(m, Xn_d, ld, idx_d, row0, batch, global_batch, train, stream); });
+}
+
+extern "C" int dcv_mlp_apply(dcv_mlp* m, void* stream) { return apply_impl(m, stream); }
+extern "C" int64_t dcv_mlp_graph_launches(const dcv_mlp* m) { return m ? m->graph_launches : 0; }
+extern "C" int dcv_mlp_set_graph(dcv_mlp* m, int32_t enable) {
+    DCV_REQUIRE(m, "dcv_mlp_set_graph: null");
+    m->graph_on = enable != 0;
+    return DCV_OK;
+}
+
 extern "C" int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                                   void* stream) {
-    int rc = dcv_mlp_forward(m, Xn_d, ld, idx_d, row0, batch, stream);
-    if (rc) return rc;
-    rc = dcv_mlp_backward(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream);
-    if (rc) return rc;
-    return dcv_mlp_apply(m, stream);
+    DCV_REQUIRE(m, "dcv_mlp_train_step: null");
+    return run_graphed(m, 0, as_stream(stream), [&] {
+        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, stream);
+        if (rc) return rc;
+        rc = backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream);
+        if (rc) return rc;
+        return apply_impl(m, stream);
+    });
 }
 
 extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                                  void* stream) {
-    int rc = dcv_mlp_forward(m, Xn_d, ld, idx_d, row0, batch, stream);
-    if (rc) return rc;
-    return dcv_mlp_backward(m, Xn_d, ld, idx_d, row0, batch, batch, 0, stream);
+    DCV_REQUIRE(m, "dcv_mlp_eval_step: null");
+    return run_graphed(m, 3, as_stream(stream), [&] {
+        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, stream);
+        if (rc) return rc;
+        return backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 0, stream);
+    });
 }
 
 extern "C" int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld, const float* tmean_d, const float* tevecs_d,

@@ -379,6 +379,14 @@ class Mlp:
     def apply(self):
         check(self.lib.dcv_mlp_apply(self.h, _stream()), "dcv_mlp_apply")
 
+    def set_graph(self, enable: bool):
+        """Opt in to hipGraph launches of the step entry points (needs a non-null stream)."""
+        check(self.lib.dcv_mlp_set_graph(self.h, 1 if enable else 0), "dcv_mlp_set_graph")
+
+    def graph_launches(self) -> int:
+        """Calls of train_step / forward / backward / eval_step that went out as one hipGraph launch."""
+        return int(self.lib.dcv_mlp_graph_launches(self.h))
+
     def train_step(self, Xn, idx=None, row0=0, batch=None):
         batch = int(batch if batch is not None else idx.numel())
         check(self.lib.dcv_mlp_train_step(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_train_step")
@@ -403,6 +411,10 @@ class Mlp:
     # -- per-kernel timing (HIP events on the launch stream)
     def profile_begin(self, max_steps: int, level: int = 1):
         check(self.lib.dcv_mlp_profile_begin(self.h, int(max_steps), int(level)), "dcv_mlp_profile_begin")
+
+    def profile_pause(self, paused: bool):
+        """Steps issued while paused carry no events (a timed region can be sampled)."""
+        check(self.lib.dcv_mlp_profile_pause(self.h, 1 if paused else 0), "dcv_mlp_profile_pause")
 
     def profile_end(self):
         """{(layer, kind): (total_ms, launches)} with kind in 'fwd' | 'wgrad' | 'dgrad'."""

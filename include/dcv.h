@@ -210,6 +210,16 @@ int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, int32_t* n_
  * milliseconds and launch counts per class (3*n_layers entries each). */
 int dcv_mlp_profile_begin(dcv_mlp* m, int32_t max_steps, int32_t level);
 int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h);
+/* Between begin and end: steps issued while paused carry no events (and may go out as graphs), so a timed region can
+ * be sampled, e.g. every fourth step. */
+int dcv_mlp_profile_pause(dcv_mlp* m, int32_t paused);
+
+/* With DCV_GRAPH=1 in the environment and a non-null stream, dcv_mlp_train_step / forward / backward(train) /
+ * eval_step capture their launch sequence into a hipGraph, update the slot's instantiated graph in place (same
+ * topology, new arguments) and launch it once.  Off by default: measured, it does not shorten the step on this
+ * platform.  Returns how many calls went out as a graph launch. */
+int64_t dcv_mlp_graph_launches(const dcv_mlp* m);
+int dcv_mlp_set_graph(dcv_mlp* m, int32_t enable);   /* per-engine switch (default: DCV_GRAPH=1 in the environment) */
 
 /* Whole-matrix inference (project / normalize_cv): y = layers[0..latent_layer)(xn);
  * Deep-TICA additionally y = (y - tmean) @ tevecs (both d floats / d*d row-major, device,

@@ -385,3 +385,49 @@ def test_data_parallel_two_ranks_match_single_process(tmp_path):
         np.testing.assert_allclose(z["loss"], ref_loss, rtol=1e-5, atol=1e-6)
         for i, (w, _) in enumerate(ref_lin):
             np.testing.assert_allclose(z[f"w{i}"], w, atol=2e-5)
+
+
+def test_graphed_steps_match_plain_launches():
+    """With step graphs switched on (dcv_mlp_set_graph / DCV_GRAPH=1), on a capturing-capable (non-null) stream a step is captured into a hipGraph whose
+    instantiation is updated in place every call (dcv_mlp_train_step / forward / backward / eval_step); on the null
+    stream the same kernels are launched one by one.  Same kernels, same order: the parameters after several steps, with changing batch offsets,
+    an evaluation step in between and a changing batch size, must be bit-identical."""
+    from deep_cartograph_amd import hip
+
+    dims, lag = [64, 32, 16, 3], 5
+    acts = ["leaky_relu", "leaky_relu", None]
+    X = ar_features(6000, dims[0], 31)
+    Xn, _, _ = normalized(X)
+    torch.manual_seed(6)
+    lins = linears_of(onn.feed_forward(dims, acts))
+    Xd = torch.from_numpy(Xn).cuda()
+
+    def run(stream):
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=1024, lag=lag, tica_reg=1e-6, lr=1e-3)
+        push_params(eng, lins)
+        eng.reset_log(64)
+        eng.set_graph(True)
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.default_stream())
+        with ctx:
+            for i in range(5):
+                eng.train_step(Xd, row0=100 * i, batch=1024)
+            eng.eval_step(Xd, row0=3000, batch=1024)
+            for i in range(3):                       # split calls, as the data-parallel path makes them
+                eng.forward(Xd, row0=50 * i, batch=768)
+                eng.backward(Xd, row0=50 * i, batch=768, global_batch=768, train=True)
+                eng.apply()
+            eng.train_step(Xd, row0=7, batch=1024)
+        torch.cuda.synchronize()
+        out = eng.get_linears(), eng.read_log()[:10].copy(), eng.graph_launches()
+        eng.close()
+        return out
+
+    plain, plain_log, n_plain = run(None)
+    side = torch.cuda.Stream()
+    graphed, graphed_log, n_graphed = run(side)
+    assert n_plain == 0          # the default stream cannot capture
+    assert n_graphed >= 8        # every call after the first of each kind went out as a graph
+    for (w0, b0), (w1, b1) in zip(plain, graphed):
+        np.testing.assert_array_equal(w0, w1)
+        np.testing.assert_array_equal(b0, b1)
+    np.testing.assert_array_equal(plain_log, graphed_log)

@@ -55,17 +55,18 @@ def c3(n=5_000_000, F=256, lag=10):
     # end-to-end calculators (fit + normalise CV + project training frames; no file output)
     for cv in ("tica", "htica"):
         cfg = {"dimension": 2, "lag_time": lag, "features_normalization": None, "num_subspaces": 10, "subspaces_dimension": 5}
-        calc = cv_calculators_map[cv](cfg, "/tmp/dcv_bench_out")
-        sync()
-        t0 = time.perf_counter()
-        calc.set_training_matrix(X)
-        calc.create_output_folders()
-        calc.compute_cv()
-        calc.set_labels()
-        calc.normalize_cv()
-        proj = calc.project_data(calc.training_data, normalize_data=False)
-        sync()
-        dt = time.perf_counter() - t0
+        for rep in range(3):   # the first pass pays the allocator's first touch of the work buffers; report the last
+            calc = cv_calculators_map[cv](cfg, "/tmp/dcv_bench_out")
+            sync()
+            t0 = time.perf_counter()
+            calc.set_training_matrix(X)
+            calc.create_output_folders()
+            calc.compute_cv()
+            calc.set_labels()
+            calc.normalize_cv()
+            proj = calc.project_data(calc.training_data, normalize_data=False)
+            sync()
+            dt = time.perf_counter() - t0
         out[f"{cv}_fit_project_s"] = dt
         out[f"{cv}_frames_per_s"] = n / dt
     del X

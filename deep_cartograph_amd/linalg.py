@@ -3,9 +3,22 @@ SURVEY.md section 8b): the generalised eigenproblem of TICA and the PCA eigen-de
 in float64 on the covariance blocks produced (and all-reduced) by the HIP kernels."""
 from __future__ import annotations
 
+import contextlib
+import os
 from typing import Tuple
 
 import numpy as np
+
+
+def _few_threads():
+    """F x F solves with F of a few hundred are slower -- and on a 128-core host erratically so (tens of ms of
+    thread start-up and contention) -- when the BLAS spreads them over every core: cap the pool for their duration."""
+    try:
+        from threadpoolctl import threadpool_limits
+
+        return threadpool_limits(limits=min(8, os.cpu_count() or 1))
+    except Exception:   # threadpoolctl missing: unrestricted, only slower
+        return contextlib.nullcontext()
 
 
 def tica_eigh(C0: np.ndarray, Ct: np.ndarray, reg: float = 1e-6, n_eig: int = 0) -> Tuple[np.ndarray, np.ndarray]:
@@ -16,14 +29,15 @@ def tica_eigh(C0: np.ndarray, Ct: np.ndarray, reg: float = 1e-6, n_eig: int = 0)
     C0 = np.asarray(C0, dtype=np.float64)
     Ct = np.asarray(Ct, dtype=np.float64)
     n = C0.shape[0]
-    L = np.linalg.cholesky(C0 + reg * np.eye(n))
-    Li = np.linalg.inv(L)
-    A = Li @ Ct @ Li.T
-    A = 0.5 * (A + A.T)
-    evals, V = np.linalg.eigh(A)
-    order = np.argsort(evals)[::-1]
-    evals = evals[order]
-    V = Li.T @ V[:, order]
+    with _few_threads():
+        L = np.linalg.cholesky(C0 + reg * np.eye(n))
+        Li = np.linalg.inv(L)
+        A = Li @ Ct @ Li.T
+        A = 0.5 * (A + A.T)
+        evals, V = np.linalg.eigh(A)
+        order = np.argsort(evals)[::-1]
+        evals = evals[order]
+        V = Li.T @ V[:, order]
     V = V / np.sqrt((V * V).sum(axis=0))
     sign = np.sign(V[0, :])
     sign[sign == 0] = 1.0
@@ -38,7 +52,8 @@ def pca_components(C: np.ndarray, dim: int) -> np.ndarray:
     column flipped so that its first entry is non-negative -- what sklearn PCA(n_components)
     .components_.T becomes after the reference's sign rule (cv_calculator.py:2204-2215)."""
     C = np.asarray(C, dtype=np.float64)
-    w, V = np.linalg.eigh(0.5 * (C + C.T))
+    with _few_threads():
+        w, V = np.linalg.eigh(0.5 * (C + C.T))
     order = np.argsort(w)[::-1][:dim]
     W = V[:, order].copy()
     for i in range(W.shape[1]):

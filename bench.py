@@ -177,7 +177,7 @@ def main():
             if dist is None:
                 eng.eval_step(Xn, row0=r0, batch=lb)
             else:
-                eng.forward(Xn, row0=r0, batch=lb)
+                eng.forward(Xn, row0=r0, batch=lb, train=False)
                 dist.all_reduce(stats_v, op=dist.ReduceOp.SUM)
                 eng.backward(Xn, row0=r0, batch=lb, global_batch=a.batch, train=False)
 

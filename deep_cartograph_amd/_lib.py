@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdcv.so")
 
 DCV_MAX_LAYERS = 16
-ACT = {None: 0, "linear": 0, "leaky_relu": 1, "relu": 2, "tanh": 3, "elu": 4, "softplus": 5}
+ACT = {None: 0, "linear": 0, "leaky_relu": 1, "relu": 2, "tanh": 3, "elu": 4, "softplus": 5, "shifted_softplus": 6, "custom_sigmoid": 7}
+OPTIMIZER = {"Adam": 0, "AdamW": 1, "SGD": 2, "RMSprop": 3, "Adagrad": 4}
 MODEL_DEEPTICA = 1
 MODEL_AE = 2
 
@@ -28,6 +29,17 @@ class MlpDesc(C.Structure):
         ("beta2", C.c_double),
         ("eps", C.c_double),
         ("weight_decay", C.c_double),
+        ("optimizer", C.c_int32),
+        ("amsgrad", C.c_int32),
+        ("nesterov", C.c_int32),
+        ("centered", C.c_int32),
+        ("momentum", C.c_double),
+        ("dampening", C.c_double),
+        ("alpha", C.c_double),
+        ("lr_decay", C.c_double),
+        ("initial_accumulator_value", C.c_double),
+        ("dropout", C.c_float * DCV_MAX_LAYERS),
+        ("seed", C.c_uint64),
     ]
 
 
@@ -61,9 +73,13 @@ SIGNATURES = {
     "dcv_mlp_set_params": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_get_params": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_set_lr": (C.c_int, [_P, C.c_double]),
+    "dcv_mlp_set_momentum": (C.c_int, [_P, C.c_double]),
+    "dcv_mlp_dropout_mask": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
+    "dcv_mlp_dropout_step": (_I64, [_P]),
+    "dcv_gemm_tn_split": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "dcv_mlp_set_row_sharing": (C.c_int, [_P, _I32]),
     "dcv_mlp_set_feature_range": (C.c_int, [_P, _P, _P]),
-    "dcv_mlp_forward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
+    "dcv_mlp_forward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "dcv_mlp_stats": (_P, [_P]),
     "dcv_mlp_stats_len": (_I32, [_P]),
     "dcv_mlp_backward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I64, _I32, _P]),
@@ -114,8 +130,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.dcv_abi_version()
-    if ver != 1:
-        raise DcvError(f"libdcv.so ABI version {ver}, expected 1")
+    if ver != 2:
+        raise DcvError(f"libdcv.so ABI version {ver}, expected 2 (rebuild: make -C deep_cartograph_amd/csrc)")
     _lib = lib
     return lib
 

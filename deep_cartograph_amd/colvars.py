@@ -114,19 +114,37 @@ def _read_text(path: str, names: Sequence[str], workers: Optional[int] = None, m
 
 def load_feature_matrix(colvars_paths: Union[str, Sequence[str]], features_list: Optional[Sequence[str]] = None,
                         start: int = 0, stop: Optional[int] = None, stride: int = 1,
-                        ) -> Tuple[np.ndarray, List[str], np.ndarray]:
+                        shard: Optional[Tuple[int, int]] = None) -> Tuple[np.ndarray, List[str], np.ndarray]:
     """(X float32 C-contiguous [frames, features], feature names, traj_label per frame).
 
     Same selection rules as ``create_dataframe_from_files``; raises on NaNs in a file, on a
-    missing requested feature and on files whose columns disagree when no list is given."""
+    missing requested feature and on files whose columns disagree when no list is given.
+
+    ``shard = (world, rank)``: X holds only this rank's contiguous block of the concatenated frames
+    (parallel.shard_bounds; rows outside it are never materialised -- a memory-mapped .npy is sliced, not
+    read); the labels returned are still those of ALL frames, so that every rank can split a gathered
+    projection by trajectory."""
     if isinstance(colvars_paths, str):
         colvars_paths = [colvars_paths]
     blocks, labels = [], []
     ref_names: Optional[List[str]] = None
-    for file_index, path in enumerate(colvars_paths):
+    mats = []
+    for path in colvars_paths:
         if not os.path.exists(path):
             raise FileNotFoundError(f"Colvars file not found: {path}")
-        mat, names = _read_matrix(path, start, stop, stride)
+        mats.append(_read_matrix(path, start, stop, stride))
+    lo, hi = 0, sum(m.shape[0] for m, _ in mats)
+    if shard is not None:
+        from .parallel import shard_bounds
+
+        lo, hi = shard_bounds(hi, int(shard[0]), int(shard[1]))
+    offset = 0
+    for file_index, path in enumerate(colvars_paths):
+        mat, names = mats[file_index]
+        labels.append(np.full(mat.shape[0], file_index, dtype=np.int64))
+        a, b = min(max(lo - offset, 0), mat.shape[0]), min(max(hi - offset, 0), mat.shape[0])
+        offset += mat.shape[0]
+        mat = mat[a:b]
         keep = [i for i, n in enumerate(names) if _DEFAULT_FILTER.search(n)]
         kept_names = [names[i] for i in keep]
         if features_list:
@@ -148,7 +166,6 @@ def load_feature_matrix(colvars_paths: Union[str, Sequence[str]], features_list:
         if np.isnan(block).any():
             raise ValueError(f"Clean your data! NaNs found in {path}")
         blocks.append(block)
-        labels.append(np.full(block.shape[0], file_index, dtype=np.int64))
     if not blocks:
         raise ValueError("No colvars files given.")
     X = blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)

@@ -56,11 +56,13 @@ def merge_configurations(common_config: Dict, specific_config: Optional[Dict]) -
 
 
 def closest_power_of_two(n: int) -> int:
-    """Largest power of two <= n (used to clamp the batch size, cv_calculator.py:1306-1307)."""
-    p = 1
-    while p * 2 <= n:
-        p *= 2
-    return p
+    """Closest power of two strictly below n: 2**floor(log2 n), halved when n is itself a power of
+    two (reference common.py:645-666; clamps the batch size, cv_calculator.py:1306-1307).  The
+    reference yields 0.5 for n = 1; 1 is returned here (a batch cannot be smaller)."""
+    if n <= 1:
+        return 1
+    p = 1 << (int(n).bit_length() - 1)
+    return p // 2 if p == n else p
 
 
 def zip_files(output_zip_path: str, *paths: str) -> None:

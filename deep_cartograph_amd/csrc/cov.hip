@@ -101,7 +101,7 @@ extern "C" int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int6
     // -1e-5 relative at 4096 rows (tools/split_bench.hip) against an unbiased +-3e-6 here, and TICA eigenvectors are
     // held to 1e-5.
     const Operand op = make_operand(X_d, ld, F, identity_rows(), shift_d);
-    EpiSlab epi{slab, F, F, p.nb, 0, quad_ok(slab, F)};
+    EpiSlab epi{slab, F, F, p.nb, 0, quad_ok(slab, F), p.splits};   // p.splits slabs are what cov_plan sized the workspace for
     if (p.nb == 2)
         rc = launch_gemm_cfg<kTN, CfgCovT<false>, 2, EpiSlab>(op, op, lag, F, F, n_pairs, p.k_chunk, epi, s);
     else

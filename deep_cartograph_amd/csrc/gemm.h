@@ -1071,6 +1071,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 } else {
                     epi.template transform<EQ>(v, side, cc);
                 }
+                // dropout (training only; workgroup-uniform switch): the keep mask of element (row, col) is a pure
+                // function of (seed, step, layer, row, col), so the dgrad epilogue recomputes the forward's mask
+                if constexpr (Epi::kDrop) {
+                    if (epi.drop.thr != 0u) epi.drop.template apply<EQ>(v, mbase + r0 + qc * RPP, RPP, col);
+                }
                 if constexpr (Epi::kMaskOut) {
                     if (epi.mask != nullptr) store_sign_mask<EQ>(epi.mask, v, seg0, wave, lane);
                 }

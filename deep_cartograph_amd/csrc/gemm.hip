@@ -19,3 +19,12 @@ extern "C" int dcv_gemm_f32(int32_t mode, const float* A_d, int64_t lda, const f
         default: set_error("dcv_gemm_f32: mode %d", mode); return DCV_EINVAL;
     }
 }
+
+extern "C" int dcv_gemm_tn_split(const float* A_d, int64_t lda, const float* B_d, int64_t ldb, float* slab_d, int64_t slab_cap,
+                                 int64_t M, int64_t N, int64_t K, int64_t k_chunk, void* stream) {
+    DCV_REQUIRE(A_d && B_d && slab_d && M > 0 && N > 0 && K > 0 && k_chunk > 0 && slab_cap > 0, "dcv_gemm_tn_split: bad arguments");
+    const Operand A = make_operand(A_d, lda, 0);
+    const Operand B = make_operand(B_d, ldb, 0);
+    EpiSlab epi{slab_d, M, N, 1, 0, quad_ok(slab_d, N), slab_cap};
+    return launch_gemm<kTN, EpiSlab>(A, B, M, N, K, k_chunk, epi, as_stream(stream));
+}

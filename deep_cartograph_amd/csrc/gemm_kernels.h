@@ -7,6 +7,7 @@
 namespace dcv {
 
 // ------------------------------------------------------------------ activations
+constexpr float kSoftplus0 = 0.6931471824645996f;   // F.softplus(torch.zeros(1)).item(): float32 log1p(exp(0))
 __device__ __forceinline__ float act_fwd(int act, float z) {
     switch (act) {
         case DCV_ACT_LEAKY_RELU: return z > 0.f ? z : 0.01f * z;
@@ -14,6 +15,8 @@ __device__ __forceinline__ float act_fwd(int act, float z) {
         case DCV_ACT_TANH: return tanhf(z);
         case DCV_ACT_ELU: return z > 0.f ? z : expm1f(z);
         case DCV_ACT_SOFTPLUS: return z > 20.f ? z : log1pf(expf(z));
+        case DCV_ACT_SHIFTED_SOFTPLUS: return (z > 20.f ? z : log1pf(expf(z))) - kSoftplus0;   // mlcolvar Shifted_Softplus
+        case DCV_ACT_CUSTOM_SIGMOID: return 1.f / (1.f + expf(-3.f * z));                       // mlcolvar Custom_Sigmoid(p=3)
         default: return z;
     }
 }
@@ -25,9 +28,49 @@ __device__ __forceinline__ float act_grad_from_out(int act, float h) {
         case DCV_ACT_TANH: return 1.f - h * h;
         case DCV_ACT_ELU: return h > 0.f ? 1.f : h + 1.f;
         case DCV_ACT_SOFTPLUS: return h > 20.f ? 1.f : 1.f - expf(-h);
+        case DCV_ACT_SHIFTED_SOFTPLUS: return 1.f - expf(-(h + kSoftplus0));   // sigmoid(z) = 1 - exp(-softplus(z))
+        case DCV_ACT_CUSTOM_SIGMOID: return 3.f * h * (1.f - h);
         default: return 1.f;
     }
 }
+
+// ------------------------------------------------------------------ dropout
+// torch.nn.Dropout(p) in training mode: y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) per element.  The keep bit
+// of element (row, col) of layer `layer` at training step `step` is bit-reproducible from a counter-based generator
+// (Philox-4x32, 7 rounds; one call covers the 4 columns of a 16-byte row segment): nothing is stored, the backward
+// pass recomputes the mask of the forward.  (The reference draws its masks from torch's CPU generator -- a different
+// stream; parity is exact GIVEN the mask, which dcv_mlp_dropout_mask hands to the tests.)
+__device__ __forceinline__ uint4 philox4x32_7(uint4 c, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k0, lo1, hi0 ^ c.w ^ k1, lo0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+struct DropCfg {
+    uint32_t thr;     // keep iff draw >= thr ; thr = p * 2^32 ; 0 = dropout off
+    float scale;      // 1 / (1 - p)
+    uint32_t k0, k1;  // seed
+    uint32_t layer, step;
+    // keep * scale multipliers of columns col .. col + 3 (col % 4 == 0) of row `row`
+    __device__ __forceinline__ float4 mult(int64_t row, int64_t col) const {
+        const uint4 u = philox4x32_7(make_uint4((uint32_t)row, (uint32_t)(col >> 2), layer, step), k0, k1);
+        return make_float4(u.x >= thr ? scale : 0.f, u.y >= thr ? scale : 0.f, u.z >= thr ? scale : 0.f, u.w >= thr ? scale : 0.f);
+    }
+    template <int N>
+    __device__ __forceinline__ void apply(float4 (&v)[N], int64_t row0, int row_step, int64_t col) const {
+#pragma unroll
+        for (int q = 0; q < N; ++q) {
+            const float4 k = mult(row0 + (int64_t)q * row_step, col);
+            v[q].x *= k.x; v[q].y *= k.y; v[q].z *= k.z; v[q].w *= k.w;
+        }
+    }
+};
+constexpr DropCfg kNoDrop{0u, 1.f, 0u, 0u, 0u, 0u};
 
 // ------------------------------------------------------------------ epilogues
 // The activation switch is hoisted out of the element loops: one uniform branch per workgroup.
@@ -44,6 +87,7 @@ __device__ __forceinline__ void map_quads(float4 (&v)[N], F f) {
 __device__ __forceinline__ float f4c(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 struct EpiStore {  // C = acc
+    static constexpr bool kDrop = false;
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = false;
@@ -58,7 +102,8 @@ struct EpiStore {  // C = acc
     __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
     __device__ __forceinline__ void one(int, int64_t r, int64_t c, float v) const { C[r * ldc + c] = v; }
 };
-struct EpiBiasAct {  // H = act(acc + bias[col])
+struct EpiBiasAct {  // H = dropout(act(acc + bias[col]))
+    static constexpr bool kDrop = true;
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = false;
@@ -70,6 +115,7 @@ struct EpiBiasAct {  // H = act(acc + bias[col])
     int act;
     bool vec;
     unsigned long long* mask = nullptr;   // optional sign mask of H (ReLU family), see store_sign_mask
+    DropCfg drop = kNoDrop;
     __device__ __forceinline__ float4 colconst(int64_t c, int nvalid) const {
         return bias ? load_quad(bias + c, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -123,6 +169,7 @@ __device__ __forceinline__ int butterfly_sum(float (&x)[MAXN], int lane, int& ba
 // element: a thread's 4-column partial dot products are summed over the lanes that share its rows.
 template <int DMAX>
 struct EpiBiasActHead {
+    static constexpr bool kDrop = true;
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = true;
@@ -139,6 +186,7 @@ struct EpiBiasActHead {
     int D, act2;
     float* Z;          // [M][ldz]
     int64_t ldz;
+    DropCfg drop = kNoDrop;
     __device__ __forceinline__ float4 colconst(int64_t c, int nvalid) const {
         return bias ? load_quad(bias + c, nvalid, vec) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -178,7 +226,8 @@ struct EpiBiasActHead {
     __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
     __device__ __forceinline__ void one(int, int64_t, int64_t, float) const {}
 };
-struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> bias-gradient partials
+struct EpiActGrad {  // dZ = acc * act'(H) [* dropout mask of H] ; column sums of dZ per row tile -> bias-gradient partials
+    static constexpr bool kDrop = true;
     static constexpr bool kColSum = true;
     static constexpr bool kSide = true;
     static constexpr bool kHead = false;
@@ -194,6 +243,8 @@ struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> b
     bool vec;
     const unsigned long long* mask = nullptr;   // sign mask of H written by the forward of the same tile shape: H is not read
     float slope = 0.f;                          // derivative where H <= 0 (0.01 leaky ReLU, 0 ReLU)
+    DropCfg drop = kNoDrop;                     // dropout of the layer that produced H: the stored H is act(z) * keep / (1 - p)
+    float hscale = 1.f;                         // 1 - p: stored kept value -> act(z)
     template <int N>
     __device__ __forceinline__ void apply_mask(float4 (&v)[N], int64_t seg0, int wave, int lane) const {
 #pragma unroll
@@ -213,7 +264,7 @@ struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> b
             case DCV_ACT_LEAKY_RELU: map_quads<N>(v, [&](float x, int c, int q) { return f4c(h[q], c) > 0.f ? x : 0.01f * x; }); break;
             case DCV_ACT_RELU: map_quads<N>(v, [&](float x, int c, int q) { return f4c(h[q], c) > 0.f ? x : 0.f; }); break;
             case DCV_ACT_NONE: break;
-            default: map_quads<N>(v, [&](float x, int c, int q) { return x * act_grad_from_out(act, f4c(h[q], c)); }); break;
+            default: map_quads<N>(v, [&](float x, int c, int q) { return x * act_grad_from_out(act, f4c(h[q], c) * hscale); }); break;
         }
     }
     __device__ __forceinline__ float* out_ptr(int, int64_t r, int64_t c) const { return C + r * ldc + c; }
@@ -221,6 +272,7 @@ struct EpiActGrad {  // dZ = acc * act'(H) ; column sums of dZ per row tile -> b
     __device__ __forceinline__ void colsum(int tile_m, int64_t c, float v) const { bpart[(int64_t)tile_m * n + c] = v; }
 };
 struct EpiSlab {  // split-K partials: slab[z][which][M][N]
+    static constexpr bool kDrop = false;
     static constexpr bool kColSum = false;
     static constexpr bool kSide = false;
     static constexpr bool kHead = false;
@@ -231,6 +283,7 @@ struct EpiSlab {  // split-K partials: slab[z][which][M][N]
     int nb;
     int64_t z;
     bool vec;
+    int64_t cap = 0;   // slabs of nb * M * N floats the buffer holds: checked against the split count at launch
     __device__ __forceinline__ float4 colconst(int64_t, int) const { return make_float4(0.f, 0.f, 0.f, 0.f); }
     template <int NN>
     __device__ __forceinline__ void transform(float4 (&)[NN], const float4 (&)[1], const float4&) const {}
@@ -341,6 +394,13 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
     const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
     DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
                 (long long)tiles, (long long)splits);
+    if constexpr (std::is_same<Epi, EpiSlab>::value) {
+        // every split writes its own slab: refuse the launch instead of writing past the caller's buffer
+        if (splits > epi.cap) {
+            set_error("gemm: %lld split-K slabs needed, the slab buffer holds %lld", (long long)splits, (long long)epi.cap);
+            return DCV_ENOMEM;
+        }
+    }
     // 16-byte loads: aligned operands; contraction-contiguous (MMAJOR) operands also need K % 4 == 0
     constexpr bool A_MM = (MODE == kNT || MODE == kNN), B_MM = (MODE == kNT);
     const bool vec = A.vec_ok && B.vec_ok && (!A_MM || K % 4 == 0) && (!B_MM || K % 4 == 0) && (MODE != kTN || d.k_chunk % 1 == 0);

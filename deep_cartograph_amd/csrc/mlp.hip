@@ -45,6 +45,12 @@ struct dcv_mlp {
     int64_t n_params;
     std::vector<LayerPlan> layers;
     float *params, *grads, *adam_m, *adam_v;
+    float* opt_aux;            // third optimiser state (amsgrad maximum / centred RMSprop gradient average) or null
+    double momentum_rt;        // beta1 (Adam family) or momentum (SGD, RMSprop): dcv_mlp_set_momentum
+    bool any_drop;             // some layer has dropout p > 0
+    bool fwd_train;            // the last forward ran in training mode (dropout active): backward must agree
+    int64_t drop_step;         // training forwards so far = step field of the next forward's dropout counters
+    int64_t cur_step;          // step field of the last training forward
     float* dZ[2];
     int64_t ld_dz;
     double* stats;             // device
@@ -159,21 +165,82 @@ __global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs
     }
 }
 
-// torch.optim.Adam (single-tensor form), fp32 state
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, int64_t n, float lr_over_bc1, float bc2_sqrt,
-                                                   float beta1, float beta2, float eps, float wd) {
+// torch.optim single-tensor updates (CPU code path of torch 2.x: _single_tensor_adam / _adamw / _sgd / _rmsprop /
+// _adagrad), fp32 state.  One thread per element; `s1`, `s2`, `s3` are the optimiser's state tensors.
+struct OptArgs {
+    int kind, flag;   // DCV_OPT_*; flag: amsgrad (Adam family), nesterov (SGD), centered (RMSprop)
+    int first;        // SGD: first step (momentum buffer := gradient)
+    float lr, b1, b2, eps, wd;
+    float c1, c2;     // Adam family: lr / (1 - b1^t), sqrt(1 - b2^t); Adagrad: c1 = lr / (1 + (t - 1) lr_decay)
+    // scalars torch forms in Python doubles and then hands to a float32 kernel: computed on the host in double and
+    // rounded once, exactly as there ((float)(1 - 0.999) is not 1.f - 0.999f)
+    float w1, w2;     // 1 - beta1 (Adam) / 1 - dampening (SGD) ; 1 - beta2 (Adam) / 1 - alpha (RMSprop)
+    float decay;      // AdamW: 1 - lr * weight_decay
+};
+__global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+                                                        float* __restrict__ s2, float* __restrict__ s3, int64_t n, OptArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float gi = g[i];
-        const float pi = p[i];
-        if (wd != 0.f) gi = fmaf(wd, pi, gi);
-        float mi = m[i], vi = v[i];
-        mi = mi + (gi - mi) * (1.f - beta1);           // exp_avg.lerp_(grad, 1 - beta1)
-        vi = vi * beta2 + (1.f - beta2) * gi * gi;     // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        m[i] = mi;
-        v[i] = vi;
-        p[i] = pi - lr_over_bc1 * (mi / denom);
+        float pi = p[i];
+        switch (a.kind) {
+            case DCV_OPT_ADAM:
+            case DCV_OPT_ADAMW: {
+                if (a.kind == DCV_OPT_ADAMW) pi = pi * a.decay;                        // param.mul_(1 - lr * weight_decay)
+                else if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);                        // grad.add(param, alpha=weight_decay)
+                float mi = s1[i], vi = s2[i];
+                mi = mi + (gi - mi) * a.w1;                                           // exp_avg.lerp_(grad, 1 - beta1)
+                vi = vi * a.b2 + a.w2 * gi * gi;                                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+                float vden = vi;
+                if (a.flag) {                                                          // amsgrad: max_exp_avg_sq = max(., exp_avg_sq)
+                    vden = fmaxf(s3[i], vi);
+                    s3[i] = vden;
+                }
+                const float denom = sqrtf(vden) / a.c2 + a.eps;
+                s1[i] = mi;
+                s2[i] = vi;
+                p[i] = pi - a.c1 * (mi / denom);                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+                break;
+            }
+            case DCV_OPT_SGD: {
+                if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+                if (a.b1 != 0.f) {                                                     // b1 = momentum, w1 = 1 - dampening
+                    float bi = a.first ? gi : s1[i] * a.b1 + a.w1 * gi;               // buf.mul_(momentum).add_(grad, alpha=1 - dampening)
+                    s1[i] = bi;
+                    gi = a.flag ? fmaf(a.b1, bi, gi) : bi;                            // nesterov: grad.add(buf, alpha=momentum)
+                }
+                p[i] = pi - a.lr * gi;
+                break;
+            }
+            case DCV_OPT_RMSPROP: {
+                if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+                float sq = s2[i] * a.b2 + a.w2 * gi * gi;                             // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
+                s2[i] = sq;
+                float avg;
+                if (a.flag) {                                                          // centered
+                    float ga = s3[i];
+                    ga = ga + (gi - ga) * a.w2;                                        // grad_avg.lerp_(grad, 1 - alpha)
+                    s3[i] = ga;
+                    avg = sqrtf(sq - ga * ga) + a.eps;                                 // addcmul(grad_avg, grad_avg, -1).sqrt_().add_(eps)
+                } else {
+                    avg = sqrtf(sq) + a.eps;
+                }
+                if (a.b1 > 0.f) {                                                      // b1 = momentum
+                    const float bi = s1[i] * a.b1 + gi / avg;                          // buf.mul_(momentum).addcdiv_(grad, avg)
+                    s1[i] = bi;
+                    p[i] = pi - a.lr * bi;
+                } else {
+                    p[i] = pi - a.lr * (gi / avg);
+                }
+                break;
+            }
+            default: {   // DCV_OPT_ADAGRAD
+                if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+                const float su = s2[i] + gi * gi;                                      // state_sum.addcmul_(grad, grad, value=1)
+                s2[i] = su;
+                p[i] = pi - a.c1 * (gi / (sqrtf(su) + a.eps));                         // param.addcdiv_(grad, std, value=-clr)
+                break;
+            }
+        }
     }
 }
 
@@ -494,7 +561,7 @@ static TicaGradFn tica_grad_fn(int d) {
 // batch, shared rows) an interior row receives both.  Multiplied by act'(F) of the last layer.
 __global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ F, int64_t ldf, int B, int d, int lag_off,
                                                       const float* __restrict__ gradp, int act, float* __restrict__ dZ,
-                                                      int64_t ldz) {
+                                                      int64_t ldz, DropCfg drop, float hscale) {
     __shared__ float s_g[kMaxTicaDim * (2 * kMaxTicaDim + 2)];
     const int np = d + 2 * d * d + d;
     for (int i = threadIdx.x; i < np; i += 256) s_g[i] = gradp[i];
@@ -530,7 +597,8 @@ __global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ 
             for (int q = 0; q < d; ++q) gl = fmaf(Gv[i * d + q], w[q], gl);
             g += gl;
         }
-        dZ[j * ldz + i] = g * act_grad_from_out(act, fj[i]);
+        if (drop.thr != 0u) g *= f4c(drop.mult(j, i & ~3), i & 3);   // F holds act(z) * keep / (1 - p)
+        dZ[j * ldz + i] = g * act_grad_from_out(act, fj[i] * hscale);
     }
 }
 
@@ -552,7 +620,8 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restr
                                                             const float* __restrict__ H, int64_t ldh, int K, int act_prev,
                                                             const float* __restrict__ W, int64_t rows_per_block,
                                                             float* __restrict__ dZ, int64_t ldz, float* __restrict__ slab,
-                                                            float* __restrict__ bpart_last, float* __restrict__ bpart_prev) {
+                                                            float* __restrict__ bpart_last, float* __restrict__ bpart_prev,
+                                                            DropCfg drop_prev, float hscale_prev) {
     constexpr int U = 4;                        // rows in flight per thread
     extern __shared__ float s_mem[];
     float* s_g = s_mem;                         // mu | Gu | Gv | c
@@ -633,8 +702,12 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restr
                 aw[j].z = fmaf(g, h[q].z, aw[j].z); aw[j].w = fmaf(g, h[q].w, aw[j].w);
                 if (c4 == 0) al[j] += g;
             }
-            z.x *= act_grad_from_out(act_prev, h[q].x); z.y *= act_grad_from_out(act_prev, h[q].y);
-            z.z *= act_grad_from_out(act_prev, h[q].z); z.w *= act_grad_from_out(act_prev, h[q].w);
+            z.x *= act_grad_from_out(act_prev, h[q].x * hscale_prev); z.y *= act_grad_from_out(act_prev, h[q].y * hscale_prev);
+            z.z *= act_grad_from_out(act_prev, h[q].z * hscale_prev); z.w *= act_grad_from_out(act_prev, h[q].w * hscale_prev);
+            if (drop_prev.thr != 0u) {   // H holds act(z) * keep / (1 - p): the same mask scales the gradient
+                const float4 k = drop_prev.mult(r, c4 * 4);
+                z.x *= k.x; z.y *= k.y; z.z *= k.z; z.w *= k.w;
+            }
             *reinterpret_cast<float4*>(dZ + r * ldz + c4 * 4) = z;
             ab.x += z.x; ab.y += z.y; ab.z += z.z; ab.w += z.w;
         }
@@ -662,7 +735,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restr
 }
 
 typedef void (*head_backward_fn_t)(const float*, int64_t, int, int, const float*, int, const float*, int64_t, int, int, const float*, int64_t,
-                                   float*, int64_t, float*, float*, float*);
+                                   float*, int64_t, float*, float*, float*, DropCfg, float);
 static head_backward_fn_t head_backward_fn(int d) {
     switch (d) {
         case 1: return head_backward_kernel<1>;
@@ -708,7 +781,7 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
 __global__ __launch_bounds__(256) void ae_dY_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Xn,
                                                     int64_t ldx, RowMap rows, int64_t R, int F,
                                                     const float* __restrict__ range, float scale, int act,
-                                                    float* __restrict__ dZ, int64_t ldz) {
+                                                    float* __restrict__ dZ, int64_t ldz, DropCfg drop, float hscale) {
     const int64_t total = R * F;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / F;
@@ -716,7 +789,24 @@ __global__ __launch_bounds__(256) void ae_dY_kernel(const float* __restrict__ Y,
         const float y = Y[r * ldy + c];
         const float x = Xn[rows.template get<true>(r) * ldx + c];
         const float rg = range[c];
-        dZ[r * ldz + c] = scale * (y - x) * rg * rg * act_grad_from_out(act, y);
+        float g = scale * (y - x) * rg * rg * act_grad_from_out(act, y * hscale);
+        if (drop.thr != 0u) g *= f4c(drop.mult(r, c & ~3), c & 3);
+        dZ[r * ldz + c] = g;
+    }
+}
+
+// test hook: the keep / (1 - p) multipliers of a layer's dropout for rows [0, rows)
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* __restrict__ out, int64_t rows, int width, DropCfg drop) {
+    const int q4 = (width + 3) / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < rows * q4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / q4;
+        const int c = (int)(i - r * q4) * 4;
+        const float4 k = drop.thr != 0u ? drop.mult(r, c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        float* o = out + r * width + c;
+        o[0] = k.x;
+        if (c + 1 < width) o[1] = k.y;
+        if (c + 2 < width) o[2] = k.z;
+        if (c + 3 < width) o[3] = k.w;
     }
 }
 
@@ -749,8 +839,24 @@ static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStre
 // sample i + lag, so the network is evaluated once on the B + lag rows row0 .. row0+B+lag-1 and both
 // halves read the shared outputs -- the same numbers as two separate passes (every row goes through the
 // same weights), about half the matrix work.  The gradient of a shared row is the sum of its two roles.
+// (Not with dropout in a training step: the reference evaluates x_t and x_lag in two forward calls with independent masks.)
 static bool shared_rows(const dcv_mlp* m, const int64_t* idx, int batch) {
-    return m->desc.model == DCV_MODEL_DEEPTICA && idx == nullptr && m->desc.lag >= 1 && m->desc.lag <= batch && !m->no_row_sharing;
+    return m->desc.model == DCV_MODEL_DEEPTICA && idx == nullptr && m->desc.lag >= 1 && m->desc.lag <= batch && !m->no_row_sharing &&
+           !(m->fwd_train && m->any_drop);
+}
+// dropout behind Linear `layer` in the current step (off in evaluation mode)
+static DropCfg drop_cfg(const dcv_mlp* m, int layer) {
+    const float p = m->desc.dropout[layer];
+    if (!m->fwd_train || !(p > 0.f)) return kNoDrop;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    if (t < 1.0) t = 1.0;
+    return DropCfg{(uint32_t)t, 1.f / (1.f - p), (uint32_t)(m->desc.seed & 0xFFFFFFFFull), (uint32_t)(m->desc.seed >> 32), (uint32_t)layer,
+                   (uint32_t)m->cur_step};
+}
+static float drop_hscale(const dcv_mlp* m, int layer) {
+    const float p = m->desc.dropout[layer];
+    return (m->fwd_train && p > 0.f) ? 1.f - p : 1.f;
 }
 static RowMap batch_rows(const dcv_mlp* m, const int64_t* idx, int64_t row0, int batch) {
     if (m->desc.model == DCV_MODEL_DEEPTICA && !shared_rows(m, idx, batch)) return RowMap{idx, row0, batch, m->desc.lag};
@@ -783,6 +889,7 @@ static size_t head_lds_bytes(int D, int K) {
 static bool head_fusable(const dcv_mlp* m) {
     static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
     if (off || m->L < 2) return false;
+    if (m->desc.dropout[m->L - 1] > 0.f) return false;   // dropout on the network output: general kernels
     const LayerPlan& p = m->layers[m->L - 1];
     const LayerPlan& q = m->layers[m->L - 2];
     const int K = p.in;
@@ -805,7 +912,7 @@ static void head_plan(const dcv_mlp* m, int64_t R, int64_t* rows_per_block, int6
 static void mlp_free(dcv_mlp* m) {
     if (!m) return;
     auto f = [](void* p) { if (p) (void)hipFree(p); };
-    f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
+    f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->opt_aux); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
     for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); }
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
@@ -826,6 +933,21 @@ static int dmalloc(T** p, size_t count) {
 
 }  // namespace dcv
 
+// optimiser state as a freshly constructed torch optimiser holds it
+static int reset_opt_state(dcv_mlp* m, hipStream_t s) {
+    const size_t bytes = m->n_params * sizeof(float);
+    DCV_CHECK_HIP(hipMemsetAsync(m->adam_m, 0, bytes, s));
+    DCV_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, bytes, s));
+    if (m->opt_aux) DCV_CHECK_HIP(hipMemsetAsync(m->opt_aux, 0, bytes, s));
+    if (m->desc.optimizer == DCV_OPT_ADAGRAD && m->desc.initial_accumulator_value != 0.0) {
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, m->adam_v, m->n_params, (float)m->desc.initial_accumulator_value);
+        DCV_CHECK_LAUNCH();
+    }
+    m->adam_t = 0;
+    m->drop_step = 0;
+    return DCV_OK;
+}
+
 static bool graph_enabled() {
     static const bool on = [] { const char* e = getenv("DCV_GRAPH"); return e && e[0] == '1'; }();
     return on;
@@ -839,7 +961,10 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     DCV_REQUIRE(L >= 1 && L <= DCV_MAX_LAYERS, "dcv_mlp_create: n_layers=%d out of range", L);
     for (int l = 0; l <= L; ++l) DCV_REQUIRE(desc->dims[l] >= 1, "dcv_mlp_create: dims[%d]=%d", l, desc->dims[l]);
     for (int l = 0; l < L; ++l)
-        DCV_REQUIRE(desc->act[l] >= DCV_ACT_NONE && desc->act[l] <= DCV_ACT_SOFTPLUS, "dcv_mlp_create: act[%d]=%d unsupported", l, desc->act[l]);
+        DCV_REQUIRE(desc->act[l] >= DCV_ACT_NONE && desc->act[l] <= DCV_ACT_CUSTOM_SIGMOID, "dcv_mlp_create: act[%d]=%d unsupported", l, desc->act[l]);
+    for (int l = 0; l < L; ++l)
+        DCV_REQUIRE(desc->dropout[l] >= 0.f && desc->dropout[l] < 1.f, "dcv_mlp_create: dropout[%d]=%g outside [0, 1)", l, (double)desc->dropout[l]);
+    DCV_REQUIRE(desc->optimizer >= DCV_OPT_ADAM && desc->optimizer <= DCV_OPT_ADAGRAD, "dcv_mlp_create: optimizer %d unknown", desc->optimizer);
     DCV_REQUIRE(desc->max_batch >= 1, "dcv_mlp_create: max_batch=%d", desc->max_batch);
     if (desc->model == DCV_MODEL_DEEPTICA) {
         DCV_REQUIRE(desc->dims[L] <= kMaxTicaDim, "dcv_mlp_create: Deep-TICA output dimension %d > %d", desc->dims[L], kMaxTicaDim);
@@ -859,6 +984,13 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->lr = desc->lr;
     m->adam_t = 0;
     m->last_batch = 0;
+    m->opt_aux = nullptr;
+    m->momentum_rt = (desc->optimizer == DCV_OPT_ADAM || desc->optimizer == DCV_OPT_ADAMW) ? desc->beta1 : desc->momentum;
+    m->any_drop = false;
+    for (int l = 0; l < L; ++l) m->any_drop = m->any_drop || desc->dropout[l] > 0.f;
+    m->fwd_train = false;
+    m->drop_step = 0;
+    m->cur_step = 0;
     m->prof_level = m->prof_cap = m->prof_step = 0;
     for (int i = 0; i < 4; ++i) { m->gexec[i] = nullptr; m->gwarm[i] = false; }
     m->graph_on = graph_enabled();
@@ -908,6 +1040,9 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     if (rc == DCV_OK) rc = dmalloc(&m->grads, (size_t)m->n_params);
     if (rc == DCV_OK) rc = dmalloc(&m->adam_m, (size_t)m->n_params);
     if (rc == DCV_OK) rc = dmalloc(&m->adam_v, (size_t)m->n_params);
+    if (rc == DCV_OK && (((desc->optimizer == DCV_OPT_ADAM || desc->optimizer == DCV_OPT_ADAMW) && desc->amsgrad) ||
+                         (desc->optimizer == DCV_OPT_RMSPROP && desc->centered)))
+        rc = dmalloc(&m->opt_aux, (size_t)m->n_params);
     if (rc == DCV_OK) rc = dmalloc(&m->dZ[0], (size_t)m->rows_cap * m->ld_dz);
     if (rc == DCV_OK) rc = dmalloc(&m->dZ[1], (size_t)m->rows_cap * m->ld_dz);
     if (rc == DCV_OK) rc = dmalloc(&m->stats, (size_t)m->stats_len);
@@ -929,8 +1064,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     }
     hipError_t e = hipMemset(m->params, 0, m->n_params * sizeof(float));
     if (e == hipSuccess) e = hipMemset(m->grads, 0, m->n_params * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(m->adam_m, 0, m->n_params * sizeof(float));
-    if (e == hipSuccess) e = hipMemset(m->adam_v, 0, m->n_params * sizeof(float));
+    if (e == hipSuccess && reset_opt_state(m, nullptr) != DCV_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemset(m->log_count, 0, sizeof(int));
     if (e == hipSuccess) e = hipMemset(m->ticket, 0, sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(m->zeros_d, 0, dl * sizeof(float));
@@ -968,10 +1102,9 @@ extern "C" int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* strea
     DCV_REQUIRE(m && params_h, "dcv_mlp_set_params: null argument");
     hipStream_t s = as_stream(stream);
     DCV_CHECK_HIP(hipMemcpyAsync(m->params, params_h, m->n_params * sizeof(float), hipMemcpyHostToDevice, s));
-    DCV_CHECK_HIP(hipMemsetAsync(m->adam_m, 0, m->n_params * sizeof(float), s));
-    DCV_CHECK_HIP(hipMemsetAsync(m->adam_v, 0, m->n_params * sizeof(float), s));
+    int rc = reset_opt_state(m, s);
+    if (rc) return rc;
     DCV_CHECK_HIP(hipStreamSynchronize(s));
-    m->adam_t = 0;
     return DCV_OK;
 }
 
@@ -992,6 +1125,31 @@ extern "C" int dcv_mlp_set_row_sharing(dcv_mlp* m, int32_t enable) {
 extern "C" int dcv_mlp_set_lr(dcv_mlp* m, double lr) {
     DCV_REQUIRE(m, "dcv_mlp_set_lr: null");
     m->lr = lr;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_set_momentum(dcv_mlp* m, double value) {
+    DCV_REQUIRE(m, "dcv_mlp_set_momentum: null");
+    m->momentum_rt = value;
+    return DCV_OK;
+}
+
+extern "C" int64_t dcv_mlp_dropout_step(const dcv_mlp* m) { return m ? m->drop_step : 0; }
+
+extern "C" int dcv_mlp_dropout_mask(dcv_mlp* m, int32_t layer, int64_t step, int64_t rows, float* out_d, void* stream) {
+    DCV_REQUIRE(m && out_d && layer >= 0 && layer < m->L && rows >= 1 && step >= 0, "dcv_mlp_dropout_mask: bad arguments");
+    const bool keep_mode = m->fwd_train;
+    const int64_t keep_step = m->cur_step;
+    m->fwd_train = true;
+    m->cur_step = step;
+    const DropCfg dc = drop_cfg(m, layer);
+    m->fwd_train = keep_mode;
+    m->cur_step = keep_step;
+    const int width = m->layers[layer].out;
+    int64_t blocks = cdiv(rows * ((width + 3) / 4), 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out_d, rows, width, dc);
+    DCV_CHECK_LAUNCH();
     return DCV_OK;
 }
 
@@ -1043,10 +1201,12 @@ static bool act_mask_enabled() {
 static bool next_layer_fusable(const dcv_mlp* m, int l) {
     static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
     if (off || l + 1 >= m->L) return false;
+    if (m->desc.dropout[l + 1] > 0.f) return false;
     return m->layers[l + 1].out <= 8 && m->layers[l].out <= 128;
 }
 
 // forward through layers [0, n_run) for `rows` logical rows
+// (dropout follows m->fwd_train, which the callers set: training forward on, everything else off)
 static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& rows_map, int64_t rows, int n_run, hipStream_t s,
                        bool for_backward = false) {
     for (int l = 0; l < n_run; ++l) {
@@ -1062,9 +1222,11 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             int rc;
             if (nx.out <= 4) {
                 EpiBiasActHead<4> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
+                epi.drop = drop_cfg(m, l);
                 rc = launch_gemm<kNT, EpiBiasActHead<4>>(A, B, rows, p.out, p.in, 0, epi, s);
             } else {
                 EpiBiasActHead<8> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
+                epi.drop = drop_cfg(m, l);
                 rc = launch_gemm<kNT, EpiBiasActHead<8>>(A, B, rows, p.out, p.in, 0, epi, s);
             }
             if (rc) return rc;
@@ -1075,6 +1237,7 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             continue;
         }
         EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act, quad_ok(p.H, p.ldh) && quad_ok(m->params + p.b_off, 4)};
+        epi.drop = drop_cfg(m, l);
         if (for_backward && p.mask && act_mask_enabled()) {   // the dgrad of the next layer reads sign(H) instead of H
             epi.mask = p.mask;
             p.mask_rows = rows;
@@ -1104,7 +1267,7 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
         (void)hipGetLastError();
         return body();
     }
-    const int64_t adam_t0 = m->adam_t;   // the only host state a replay of body() must not advance twice
+    const int64_t adam_t0 = m->adam_t, drop0 = m->drop_step;   // the host state a replay of body() must not advance twice
     const int rc = body();
     hipGraph_t g = nullptr;
     const hipError_t ec = hipStreamEndCapture(s, &g);
@@ -1114,6 +1277,7 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
         if (rc != DCV_OK) return rc;
         m->gwarm[slot] = false;   // capture failed: run this call (and relearn) without it
         m->adam_t = adam_t0;
+        m->drop_step = drop0;
         return body();
     }
     if (m->gexec[slot]) {
@@ -1133,6 +1297,7 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
     if (!m->gexec[slot]) {   // nothing was launched yet: replay as plain launches and stop trying on this slot
         m->graph_off = true;
         m->adam_t = adam_t0;
+        m->drop_step = drop0;
         return body();
     }
     DCV_CHECK_HIP(hipGraphLaunch(m->gexec[slot], s));
@@ -1141,8 +1306,10 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
 }
 
 static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
-                        void* stream) {
+                        int32_t train, void* stream) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_forward: null argument");
+    m->fwd_train = train != 0;
+    if (m->fwd_train) m->cur_step = m->drop_step++;
     DCV_REQUIRE(batch >= 1 && batch <= m->desc.max_batch, "dcv_mlp_forward: batch=%d exceeds max_batch=%d", batch, m->desc.max_batch);
     DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_forward: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
     hipStream_t s = as_stream(stream);
@@ -1187,6 +1354,10 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         return DCV_ESTATE;
     }
     DCV_REQUIRE(global_batch >= batch, "dcv_mlp_backward: global_batch=%lld < batch=%d", (long long)global_batch, batch);
+    if (m->any_drop && train && !m->fwd_train) {
+        set_error("dcv_mlp_backward: train=1 after an evaluation-mode forward (dropout masks would not match)");
+        return DCV_ESTATE;
+    }
     DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp_backward: call dcv_mlp_reset_log first");
     hipStream_t s = as_stream(stream);
     const RowMap rm = batch_rows(m, idx_d, row0, batch);
@@ -1204,7 +1375,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         fused_head = head_fusable(m);
         if (!fused_head) {
             hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
-                               lag_offset(m, idx_d, batch), m->gradp, last.act, dz_cur, m->ld_dz);
+                               lag_offset(m, idx_d, batch), m->gradp, last.act, dz_cur, m->ld_dz, drop_cfg(m, L - 1), drop_hscale(m, L - 1));
             DCV_CHECK_LAUNCH();
         }
     } else {
@@ -1217,7 +1388,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         const int64_t cap = (int64_t)num_cus() * 16;
         if (blocks > cap) blocks = cap;
         hipLaunchKernelGGL(ae_dY_kernel, dim3((unsigned)blocks), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, F, m->feat_range, scale,
-                           last.act, dz_cur, m->ld_dz);
+                           last.act, dz_cur, m->ld_dz, drop_cfg(m, L - 1), drop_hscale(m, L - 1));
         DCV_CHECK_LAUNCH();
     }
     ReduceArgs ra;
@@ -1247,7 +1418,8 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             prof_mark(m, l, 1, 0, s);
             hipLaunchKernelGGL(head_backward_fn(D), dim3((unsigned)splits), dim3(256), head_lds_bytes(D, K), s, (const float*)p.H, p.ldh,
                                (int)batch, lag_offset(m, idx_d, batch), (const float*)m->gradp, p.act, (const float*)q.H, q.ldh, K, q.act,
-                               (const float*)(m->params + p.w_off), kc, dz_nxt, m->ld_dz, p.slab, p.bpart, q.bpart);
+                               (const float*)(m->params + p.w_off), kc, dz_nxt, m->ld_dz, p.slab, p.bpart, q.bpart, drop_cfg(m, l - 1),
+                               drop_hscale(m, l - 1));
             DCV_CHECK_LAUNCH();
             prof_mark(m, l, 1, 1, s);
             prof_mark(m, l, 2, 0, s);
@@ -1269,7 +1441,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         }
         Operand A = make_operand(dz_cur, m->ld_dz, p.out);
         Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
-        EpiSlab epi{p.slab, p.out, p.in, 1, 0, quad_ok(p.slab, p.in)};
+        EpiSlab epi{p.slab, p.out, p.in, 1, 0, quad_ok(p.slab, p.in), p.max_splits};
         prof_mark(m, l, 1, 0, s);
         int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
         if (rc) return rc;
@@ -1293,6 +1465,8 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
                 eg.mask = q.mask;
                 eg.slope = q.act == DCV_ACT_LEAKY_RELU ? 0.01f : 0.f;
             }
+            eg.drop = drop_cfg(m, l - 1);
+            eg.hscale = drop_hscale(m, l - 1);
             prof_mark(m, l, 2, 0, s);
             rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks);
             if (rc) return rc;
@@ -1356,21 +1530,58 @@ static int apply_impl(dcv_mlp* m, void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_apply: null");
     hipStream_t s = as_stream(stream);
     m->adam_t += 1;
-    const double b1 = m->desc.beta1, b2 = m->desc.beta2;
-    const double bc1 = 1.0 - pow(b1, (double)m->adam_t);
-    const double bc2 = 1.0 - pow(b2, (double)m->adam_t);
+    const dcv_mlp_desc& d = m->desc;
+    const double t = (double)m->adam_t;
+    OptArgs a;
+    a.kind = d.optimizer;
+    a.flag = 0;
+    a.first = m->adam_t == 1;
+    a.lr = (float)m->lr;
+    a.b1 = a.b2 = a.c1 = a.c2 = a.w1 = a.w2 = 0.f;
+    a.decay = 1.f;
+    a.eps = (float)d.eps;
+    a.wd = (float)d.weight_decay;
+    switch (d.optimizer) {
+        case DCV_OPT_ADAM:
+        case DCV_OPT_ADAMW: {
+            const double b1 = m->momentum_rt, b2 = d.beta2;   // beta1 may be cycled by a scheduler (dcv_mlp_set_momentum)
+            a.flag = d.amsgrad ? 1 : 0;
+            a.b1 = (float)b1;
+            a.b2 = (float)b2;
+            a.w1 = (float)(1.0 - b1);
+            a.w2 = (float)(1.0 - b2);
+            a.c1 = (float)(m->lr / (1.0 - pow(b1, t)));
+            a.c2 = (float)sqrt(1.0 - pow(b2, t));
+            a.decay = (float)(1.0 - m->lr * d.weight_decay);
+            break;
+        }
+        case DCV_OPT_SGD:
+            a.flag = d.nesterov ? 1 : 0;
+            a.b1 = (float)m->momentum_rt;
+            a.w1 = (float)(1.0 - d.dampening);
+            break;
+        case DCV_OPT_RMSPROP:
+            a.flag = d.centered ? 1 : 0;
+            a.b1 = (float)m->momentum_rt;
+            a.b2 = (float)d.alpha;
+            a.w2 = (float)(1.0 - d.alpha);
+            break;
+        default:   // DCV_OPT_ADAGRAD
+            a.c1 = (float)(m->lr / (1.0 + (t - 1.0) * d.lr_decay));
+            break;
+    }
     int64_t blocks = cdiv(m->n_params, 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->params, m->grads, m->adam_m, m->adam_v, m->n_params,
-                       (float)(m->lr / bc1), (float)sqrt(bc2), (float)b1, (float)b2, (float)m->desc.eps, (float)m->desc.weight_decay);
+    hipLaunchKernelGGL(optimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->params, (const float*)m->grads, m->adam_m, m->adam_v,
+                       m->opt_aux, m->n_params, a);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }
 
 extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
-                               void* stream) {
+                               int32_t train, void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_forward: null");
-    return run_graphed(m, 1, as_stream(stream), [&] { return forward_impl(m, Xn_d, ld, idx_d, row0, batch, stream); });
+    return run_graphed(m, 1, as_stream(stream), [&] { return forward_impl(m, Xn_d, ld, idx_d, row0, batch, train, stream); });
 }
 
 extern "C" int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
@@ -1392,7 +1603,7 @@ extern "C" int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, con
                                   void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_train_step: null");
     return run_graphed(m, 0, as_stream(stream), [&] {
-        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, stream);
+        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 1, stream);
         if (rc) return rc;
         rc = backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream);
         if (rc) return rc;
@@ -1404,7 +1615,7 @@ extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, cons
                                  void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_eval_step: null");
     return run_graphed(m, 3, as_stream(stream), [&] {
-        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, stream);
+        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 0, stream);
         if (rc) return rc;
         return backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 0, stream);
     });
@@ -1418,6 +1629,7 @@ extern "C" int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t l
     hipStream_t s = as_stream(stream);
     const int n_run = m->desc.model == DCV_MODEL_AE ? m->desc.latent_layer : m->L;
     const RowMap rm = identity_rows();
+    m->fwd_train = false;
     int rc = run_forward(m, Xn_d, ld, rm, n, n_run, s);
     if (rc) return rc;
     const LayerPlan& last = m->layers[n_run - 1];
@@ -1448,6 +1660,7 @@ extern "C" int dcv_mlp_input_sensitivity(dcv_mlp* m, const float* Xn_d, int64_t 
     const int F = m->desc.dims[0];
     DCV_REQUIRE(ld >= F, "dcv_mlp_input_sensitivity: ld=%lld < F=%d", (long long)ld, F);
     const int n_run = m->desc.model == DCV_MODEL_AE ? m->desc.latent_layer : m->L;
+    m->fwd_train = false;
     int rc = run_forward(m, Xn_d, ld, identity_rows(), n, n_run, s);
     if (rc) return rc;
     const LayerPlan& last = m->layers[n_run - 1];

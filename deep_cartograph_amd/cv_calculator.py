@@ -145,8 +145,10 @@ class CVCalculator(ABC):
 
     # ------------------------------------------------------------------ data
     def _read(self, paths, features_list):
+        """Colvars files -> (this rank's contiguous block of the frames, names, labels of ALL frames)."""
         s = self.training_reading_settings
-        return load_feature_matrix(paths, features_list, start=s.get("start", 0), stop=s.get("stop"), stride=s.get("stride", 1))
+        shard = (self.comm.world, self.comm.rank) if self.comm.active else None
+        return load_feature_matrix(paths, features_list, start=s.get("start", 0), stop=s.get("stop"), stride=s.get("stride", 1), shard=shard)
 
     def load_training_data(self, train_colvars_paths: List[str], train_topology_paths: Optional[List[str]] = None,
                            ref_topology_path: Optional[str] = None, features_list: Optional[List[str]] = None):
@@ -161,7 +163,9 @@ class CVCalculator(ABC):
 
     def set_training_matrix(self, X, feature_names: Optional[List[str]] = None, labels: Optional[np.ndarray] = None):
         """Entry point for callers that already hold the (shard of the) feature matrix: a float32
-        array / tensor of this rank's frames.  A device tensor is adopted without a copy."""
+        array / tensor of this rank's frames (under torch.distributed: the rank's contiguous block, blocks
+        in rank order forming the trajectory).  A device tensor is adopted without a copy.  `labels`:
+        trajectory index of every frame of ALL ranks."""
         dev = _device()
         if isinstance(X, torch.Tensor):
             Xd = X.to(device=dev, dtype=torch.float32)
@@ -171,20 +175,31 @@ class CVCalculator(ABC):
             raise ValueError("feature matrix must be 2-D")
         self.training_data = Xd.contiguous()
         n_local, F = self.training_data.shape
-        self.training_data_labels = labels if labels is not None else np.zeros(n_local, dtype=np.int64)
         self.features_ref_labels = list(feature_names) if feature_names is not None else [f"f{i}" for i in range(F)]
         self.num_features = F
         logger.info(f"Number of features: {self.num_features}")
         raw = reduce_col_stats(hip.col_stats_raw(self.training_data), self.comm)
         self.num_frames_global = int(round(self.comm.sum_scalar(n_local, device=dev)))
+        self.training_data_labels = labels if labels is not None else np.zeros(self.num_frames_global, dtype=np.int64)
+        if len(self.training_data_labels) != self.num_frames_global:
+            raise ValueError(f"{len(self.training_data_labels)} trajectory labels for {self.num_frames_global} frames")
         self.features_stats = hip.finalize_stats(raw, self.num_frames_global)
         self.features_norm_mean, self.features_norm_range = self.prepare_normalization()
 
     def load_validation_data(self, val_colvars_paths: List[str], val_topology_paths: Optional[List[str]] = None,
                              ref_topology_path: Optional[str] = None, features_list: Optional[List[str]] = None):
+        """Separate validation set (reference :208-246): the fit then trains on ALL training samples and
+        evaluates on these frames instead of splitting (:1485-1492)."""
         logger.info("Reading validation data from colvars files...")
         X, _, _ = self._read(val_colvars_paths, features_list)
-        self.validation_data = torch.from_numpy(X).to(_device())
+        self.set_validation_matrix(X)
+
+    def set_validation_matrix(self, X):
+        dev = _device()
+        Xd = X.to(device=dev, dtype=torch.float32) if isinstance(X, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32)).to(dev)
+        if Xd.dim() != 2 or (self.num_features and Xd.shape[1] != self.num_features):
+            raise ValueError("validation matrix must be 2-D with the training features")
+        self.validation_data = Xd.contiguous()
 
     def cv_ready(self) -> bool:
         return self.cv is not None
@@ -227,6 +242,8 @@ class CVCalculator(ABC):
         if self.cv is not None:
             self.normalize_cv()
             projection = self.project_data(self.training_data, normalize_data=False)
+            if self.comm.active:   # every rank returns the projection of ALL training frames (rank order = frame order)
+                projection = _to_host(self.comm.all_gather_rows(projection.to(self.training_data.device)))
             if self.comm.rank == 0:
                 self.save_model()
             self.sensitivity_analysis()   # every rank computes (collectives inside), rank 0 writes
@@ -568,7 +585,71 @@ class HTICACalculator(LinearCalculator):
 
 
 # ======================================================================================= neural
-_OPTIM_DEFAULTS = {"lr": 1e-3, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.0}
+# torch.optim defaults of the optimisers the HIP engine implements (torch 2.x signatures)
+_OPTIMIZERS = {
+    "Adam": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False),
+    "AdamW": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False),
+    "SGD": dict(lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False),
+    "RMSprop": dict(lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False),
+    "Adagrad": dict(lr=1e-2, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10),
+}
+_IMPLEMENTATION_SWITCHES = ("foreach", "fused", "capturable", "differentiable")   # no effect on the arithmetic
+
+
+class _HostLRScheduler:
+    """torch.optim.lr_scheduler.<name> (reference :1382-1394, adjusted by :1228-1273) evaluated on the host: the very
+    torch class runs over a one-parameter optimiser of the configured type, and after each of its steps the
+    learning rate -- and beta1 / momentum, which OneCycleLR and CyclicLR cycle too -- are handed to the HIP engine.
+    Stepping follows lightning's lr_scheduler_config: interval 'step' (after every optimiser step) or 'epoch'
+    (at the end of every epoch), every `frequency`-th time; ReduceLROnPlateau receives the monitored valid_loss."""
+
+    def __init__(self, name: str, kwargs: Dict, config: Dict, opt_name: str, opt_kwargs: Dict, engine):
+        cls = getattr(torch.optim.lr_scheduler, name, None)
+        if cls is None:
+            logger.error(f"Learning rate scheduler {name} not recognized. Exiting...")
+            raise ValueError(f"Learning rate scheduler {name} not recognized.")
+        self.opt = getattr(torch.optim, opt_name)([torch.nn.Parameter(torch.zeros(1))], **opt_kwargs)
+        self.sched = cls(self.opt, **kwargs)
+        self.plateau = isinstance(self.sched, torch.optim.lr_scheduler.ReduceLROnPlateau)
+        self.interval = config.get("interval", "epoch")
+        self.frequency = max(1, int(config.get("frequency", 1)))
+        self.monitor = config.get("monitor", "valid_loss")
+        self.engine = engine
+        self.count = 0
+        self.push()
+
+    def push(self):
+        g = self.opt.param_groups[0]
+        self.engine.set_lr(float(g["lr"]))
+        if "betas" in g:
+            self.engine.set_momentum(float(g["betas"][0]))
+        elif "momentum" in g:
+            self.engine.set_momentum(float(g["momentum"]))
+
+    def lr(self) -> float:
+        return float(self.opt.param_groups[0]["lr"])
+
+    def _advance(self, metric=None):
+        self.count += 1
+        if self.count % self.frequency:
+            return
+        self.opt.step()   # no gradients: a no-op that keeps torch's call-order check quiet
+        if self.plateau:
+            if metric is None:   # lightning raises MisconfigurationException here
+                raise ValueError(f"ReduceLROnPlateau conditioned on metric {self.monitor} which is not available yet "
+                                 "(set check_val_every_n_epoch to 1)")
+            self.sched.step(metric)
+        else:
+            self.sched.step()
+        self.push()
+
+    def after_step(self):
+        if self.interval == "step":
+            self._advance()
+
+    def after_epoch(self, last_valid_loss):
+        if self.interval == "epoch":
+            self._advance(last_valid_loss)
 
 
 class NonLinear(CVCalculator):
@@ -581,8 +662,9 @@ class NonLinear(CVCalculator):
         self.training_config: Dict = self.configuration.get("training", {})
         g = self.training_config.get("general", {})
         es = self.training_config.get("early_stopping", {})
-        self.optimizer_config: Dict = self.training_config.get("optimizer", {})
-        self.lr_scheduler = self.training_config.get("lr_scheduler", None)
+        self.optimizer_config: Dict = self.training_config.get("optimizer", {}) or {}
+        self.lr_scheduler: Optional[Dict] = self.training_config.get("lr_scheduler", None) or None
+        self.lr_scheduler_config: Dict = dict(self.training_config.get("lr_scheduler_config", None) or {})
         self.model_to_save = self.training_config.get("model_to_save", "best")
         self.num_tries: int = g.get("num_tries", 10)
         self.seed: int = g.get("seed", 42)
@@ -600,69 +682,146 @@ class NonLinear(CVCalculator):
         self.decoder_config: Optional[Dict] = copy.deepcopy(dec) if dec is not None else None
         self.encoder_hidden_layers: List[int] = list(self.encoder_config.get("layers", []))
         self.decoder_hidden_layers: List[int] = list((self.decoder_config or self.encoder_config).get("layers", []))
+        self.num_training_samples: Optional[int] = None
+        self.num_validation_samples: Optional[int] = None
         self.cv_score: Optional[float] = None
         self.tries: int = 0
         self.metrics: Optional[Dict[str, list]] = None
         self.training_metrics_paths: List[str] = []
         self.weights_path: Optional[str] = None
         self.engine: Optional[hip.Mlp] = None
-        self.training_normalized: Optional[torch.Tensor] = None  # norm_in applied once (device)
+        self.training_normalized: Optional[torch.Tensor] = None    # norm_in applied once (device)
+        self.validation_normalized: Optional[torch.Tensor] = None
 
     # ---- configuration -> layer lists (reference :1155-1219)
     @staticmethod
-    def _layer_options(cfg: Dict, n_hidden: int):
-        act = list(cfg.get("activation", ["leaky_relu"] * n_hidden))
-        drop = list(cfg.get("dropout", [None] * n_hidden))
-        bn = list(cfg.get("batchnorm", [False] * n_hidden))
+    def _fit_list(values, n_hidden: int, what: str):
+        """One entry per hidden layer.  mlcolvar's FeedForward insists on exactly n entries per option and raises
+        otherwise -- which is what the schema's 3-entry defaults do to any `layers` list that is not 3 long
+        (the reference's shipped default_config.yml: layers [15, 15], no activation given).  Here a list that is
+        too long is cut and one that is too short repeats its last entry, with a warning."""
+        values = list(values)
+        if len(values) != n_hidden:
+            logger.warning(f"'{what}' has {len(values)} entries for {n_hidden} hidden layers; adjusting it.")
+            values = (values + [values[-1] if values else None] * n_hidden)[:n_hidden]
+        return values
+
+    @classmethod
+    def _layer_options(cls, cfg: Dict, n_hidden: int):
+        """(activation, dropout, batchnorm) with one entry per Linear: the hidden layers' lists plus the
+        last-layer entries, as set_up_encoder_last_layer / set_up_decoder_last_layer append them."""
+        act = cls._fit_list(cfg.get("activation", ["leaky_relu"] * n_hidden), n_hidden, "activation")
+        drop = cls._fit_list(cfg.get("dropout", [None] * n_hidden), n_hidden, "dropout")
+        bn = cls._fit_list(cfg.get("batchnorm", [False] * n_hidden), n_hidden, "batchnorm")
         act.append(cfg.get("last_layer_activation", None))
         drop.append(cfg.get("last_layer_dropout", None))
         bn.append(cfg.get("last_layer_batchnorm", False))
         if any(bn):
-            raise NotImplementedError("batch normalisation layers are not implemented by the HIP engine")
-        if any(d not in (None, 0, 0.0) for d in drop):
-            raise NotImplementedError("dropout > 0 is not implemented by the HIP engine")
-        if len(act) != n_hidden + 1:
-            raise ValueError("one activation per hidden layer expected")
+            raise NotImplementedError("batch normalisation layers are not implemented by the HIP engine "
+                                      "(set 'batchnorm' / 'last_layer_batchnorm' to False)")
+        drop = [float(d) if d else 0.0 for d in drop]
+        if any(d < 0.0 or d >= 1.0 for d in drop):
+            raise ValueError("dropout probabilities must lie in [0, 1)")
         return act, drop
 
-    def _adam_options(self):
+    def _optimizer_options(self) -> Tuple[str, Dict]:
+        """(torch.optim class name, its keyword arguments with torch's defaults filled in) -- reference :1376-1380."""
         name = self.optimizer_config.get("name", "Adam")
-        if name != "Adam":
-            raise NotImplementedError(f"optimizer {name} is not implemented by the HIP engine (Adam only)")
-        if self.lr_scheduler is not None:
-            raise NotImplementedError("learning-rate schedulers are not implemented by the HIP engine")
-        kw = dict(_OPTIM_DEFAULTS)
-        kw.update(self.optimizer_config.get("kwargs", {}) or {})
-        if kw.get("amsgrad"):
-            raise NotImplementedError("amsgrad is not implemented by the HIP engine")
-        return kw
+        if name not in _OPTIMIZERS:
+            if not hasattr(torch.optim, name):
+                raise ValueError(f"Optimizer {name} not recognized.")
+            raise NotImplementedError(f"optimizer {name} is not implemented by the HIP engine (have: {sorted(_OPTIMIZERS)})")
+        kw = dict(_OPTIMIZERS[name])
+        for k, v in (self.optimizer_config.get("kwargs", {}) or {}).items():
+            if k in _IMPLEMENTATION_SWITCHES:
+                continue
+            if k == "maximize":
+                if v:
+                    raise NotImplementedError("maximize=True is not implemented by the HIP engine")
+                continue
+            if k not in kw:
+                raise TypeError(f"{name}.__init__() got an unexpected keyword argument '{k}'")
+            kw[k] = v
+        return name, kw
+
+    @staticmethod
+    def _engine_optimizer_kwargs(name: str, kw: Dict) -> Dict:
+        out = dict(optimizer=name, lr=float(kw["lr"]), weight_decay=float(kw.get("weight_decay", 0.0)))
+        if "betas" in kw:
+            out["betas"] = (float(kw["betas"][0]), float(kw["betas"][1]))
+        for k in ("eps", "momentum", "dampening", "alpha", "lr_decay", "initial_accumulator_value"):
+            if k in kw:
+                out[k] = float(kw[k])
+        for k in ("amsgrad", "nesterov", "centered"):
+            if k in kw:
+                out[k] = bool(kw[k])
+        return out
+
+    def _scheduler_options(self, steps_per_epoch: int) -> Optional[Tuple[str, Dict, Dict]]:
+        """(name, kwargs, lr_scheduler_config) after adjust_lr_scheduler (reference :1228-1273)."""
+        if self.lr_scheduler is None:
+            return None
+        name = self.lr_scheduler.get("name", "")
+        kwargs = dict(self.lr_scheduler.get("kwargs", {}) or {})
+        config = dict(self.lr_scheduler_config)
+        if name == "OneCycleLR":
+            kwargs.setdefault("max_lr", 1e-3)
+            kwargs.setdefault("epochs", self.max_epochs)
+            kwargs.setdefault("steps_per_epoch", steps_per_epoch)
+            config["interval"] = "step"
+        elif name == "ReduceLROnPlateau":
+            kwargs.setdefault("patience", self.early_stop_patience // 4)
+            kwargs.setdefault("cooldown", self.early_stop_patience // 8)
+            config["interval"] = "epoch"
+        return name, kwargs, config
 
     # ---- data
+    def _norm_tensors(self, dev):
+        return _dev(self.features_norm_mean, dev), _dev(self.features_norm_range, dev)
+
     def set_training_matrix(self, X, feature_names=None, labels=None):
         super().set_training_matrix(X, feature_names, labels)
         dev = self.training_data.device
         # norm_in of the model, applied once: (x - mean)/range is elementwise, so the values are
         # bit-identical to applying it inside the forward pass (reference :1366-1374)
-        self.training_normalized = hip.normalize(self.training_data, _dev(self.features_norm_mean, dev),
-                                                 _dev(self.features_norm_range, dev))
+        self.training_normalized = hip.normalize(self.training_data, *self._norm_tensors(dev))
+        if self.validation_data is not None:
+            self.validation_normalized = hip.normalize(self.validation_data, *self._norm_tensors(dev))
+
+    def set_validation_matrix(self, X):
+        super().set_validation_matrix(X)
+        if self.features_norm_mean is not None:   # the training statistics normalise the validation frames too
+            self.validation_normalized = hip.normalize(self.validation_data, *self._norm_tensors(self.validation_data.device))
 
     # ---- model description, implemented by the subclasses
-    def layer_plan(self) -> Tuple[List[int], List[Optional[str]], int]:
+    def layer_plan(self) -> Tuple[List[int], List[Optional[str]], List[float], int]:
+        """(dims, activation per Linear, dropout per Linear, index of the latent layer)."""
         raise NotImplementedError
 
     def n_samples_local(self) -> int:
         raise NotImplementedError
 
+    def n_val_samples_local(self) -> int:
+        raise NotImplementedError
+
     def lag(self) -> int:
         return 0
 
-    def check_batch_size(self, n_samples: int) -> int:
-        """batch >= int(n * lengths[0]) -> closest lower power of two (reference :1278-1309)."""
-        n_train = int(n_samples * self.training_validation_lengths[0])
-        logger.info(f"Number of training samples: {n_train}")
-        logger.info(f"Number of validation samples: {n_samples - n_train}")
-        if self.batch_size >= n_train:
-            self.batch_size = closest_power_of_two(n_train)
+    def check_num_samples(self):
+        """reference :1278-1295: counted in FRAMES (len(self.training_data)), also for time-lagged pairs."""
+        if self.validation_data is not None:
+            self.num_training_samples = self.num_frames_global
+            self.num_validation_samples = int(round(self.comm.sum_scalar(self.validation_data.shape[0], device=self.validation_data.device)))
+        else:
+            self.num_training_samples = int(self.num_frames_global * self.training_validation_lengths[0])
+            self.num_validation_samples = self.num_frames_global - self.num_training_samples
+        logger.info(f"Number of training samples: {self.num_training_samples}")
+        logger.info(f"Number of validation samples: {self.num_validation_samples}")
+
+    def check_batch_size(self) -> int:
+        """batch >= number of training samples -> the power of two below it (reference :1297-1309)."""
+        if self.batch_size >= self.num_training_samples:
+            self.batch_size = closest_power_of_two(self.num_training_samples)
             logger.warning(f"The batch size is larger than the number of samples in the training set. "
                            f"Setting the batch size to the closest power of two: {self.batch_size}")
         return self.batch_size
@@ -696,20 +855,23 @@ class NonLinear(CVCalculator):
         bs = batch_size if batch_size > 0 else len(idx)
         return [("idx", idx[i:i + bs].to(dev)) for i in range(0, len(idx), bs)]
 
+    @staticmethod
+    def _part_len(part) -> int:
+        return part[1] if isinstance(part, tuple) else len(part)
+
     def _init_linears(self, dims):
         """torch.nn.Linear default initialisation in construction order, consuming the global
         RNG exactly as create_model() does."""
         lins = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
         return [(l.weight.detach().numpy().copy(), l.bias.detach().numpy().copy()) for l in lins]
 
-    def _step(self, kind, batch, train: bool, global_batch_of):
-        Xn = self.training_normalized
+    def _step(self, Xn, batch, train: bool, global_batch_of):
         kw = dict(idx=batch[1]) if batch[0] == "idx" else dict(row0=batch[1], batch=batch[2])
         n = int(batch[1].numel()) if batch[0] == "idx" else int(batch[2])
         if not self.comm.active:
             (self.engine.train_step if train else self.engine.eval_step)(Xn, **kw)
             return
-        self.engine.forward(Xn, **kw)
+        self.engine.forward(Xn, train=train, **kw)
         self.comm.sum_(self._stats_view)
         self.engine.backward(Xn, global_batch=global_batch_of(n), train=train, **kw)
         if train:
@@ -724,24 +886,36 @@ class NonLinear(CVCalculator):
 
     def train(self) -> bool:
         """Multi-try training driver (reference :1456-1553): seed + try, split, model init,
-        epochs with validation, early stopping, best / last snapshot; lowest score wins."""
+        epochs with validation, early stopping, best / last snapshot; lowest score wins.  As there, a try
+        that raises is logged and the next one runs; no valid try -> False (the CV is skipped)."""
+        logger.info(f"Training {cv_names_map[self.cv_name]} ...")
         dev = self.training_data.device
-        dims, acts, latent = self.layer_plan()
-        opt = self._adam_options()
+        try:
+            dims, acts, drops, latent = self.layer_plan()
+            opt_name, opt_kw = self._optimizer_options()
+        except Exception as e:
+            logger.error(f"{cv_names_map[self.cv_name]} cannot be set up: {e}")
+            return False
+        separate_val = self.validation_data is not None
+        if separate_val and self.validation_normalized is None:
+            self.validation_normalized = hip.normalize(self.validation_data, *self._norm_tensors(dev))
         n_local = self.n_samples_local()
+        n_val_local = self.n_val_samples_local() if separate_val else 0
         if self.comm.active:  # identical batch plans on every rank: use the smallest shard size
             n_local = int(self.comm.min_(torch.tensor([n_local], dtype=torch.int64, device=dev)).item())
-        n_global = n_local * self.comm.world
-        self.check_batch_size(n_global)
+            n_val_local = int(self.comm.min_(torch.tensor([n_val_local], dtype=torch.int64, device=dev)).item())
+        if n_local < 1 or (separate_val and n_val_local < 1):
+            logger.error("Not enough samples to train on.")
+            return False
+        self.check_num_samples()
+        self.check_batch_size()
         world = self.comm.world
         local_bs = max(1, self.batch_size // world) if self.batch_size > 0 else 0
         best = None
         for try_num in range(1, self.num_tries + 1):
             self.tries = try_num
             try:
-                result = self._train_once(try_num, dims, acts, latent, opt, n_local, local_bs, dev)
-            except NotImplementedError:
-                raise
+                result = self._train_once(try_num, dims, acts, drops, latent, opt_name, opt_kw, n_local, n_val_local, local_bs, dev)
             except Exception as e:
                 logger.error(f"Training try {try_num} failed with an exception: {e}")
                 continue
@@ -761,24 +935,38 @@ class NonLinear(CVCalculator):
         logger.info(f"Best model score across {self.num_tries} tries: {best['score']:.5f}")
         return True
 
-    def _train_once(self, try_num, dims, acts, latent, opt, n_local, local_bs, dev):
+    def _train_once(self, try_num, dims, acts, drops, latent, opt_name, opt_kw, n_local, n_val_local, local_bs, dev):
         seed = self.seed + try_num
         import random
 
         random.seed(seed)
         np.random.seed(seed % (2 ** 32))
         gen = torch.manual_seed(seed)           # seed_everything + DictModule(generator=manual_seed(seed))
-        linears = self._init_linears(dims)      # create_model() (no LR scheduler: model first, split second)
-        parts = self._split(n_local, self.training_validation_lengths, self.random_split, gen)
-        parts = [p if isinstance(p, tuple) or self.shuffle else p.to(dev) for p in parts]  # index plans live on the GPU
-        train_part, val_part = parts[0], parts[1]
-        bs = local_bs if local_bs > 0 else max(len(train_part) if not isinstance(train_part, tuple) else train_part[1], 1)
+        separate_val = self.validation_data is not None
+        # RNG order (SURVEY.md Appendix A.6 i): create_model() first, the split inside trainer.fit second --
+        # unless a scheduler is configured, whose _adjust_lr_scheduler_from_datamodule splits before the model exists
+        split_first = self.lr_scheduler is not None and not separate_val
+        parts = None
+        if split_first:
+            parts = self._split(n_local, self.training_validation_lengths, self.random_split, gen)
+        linears = self._init_linears(dims)
+        if separate_val:       # DictLoader over the whole training set and over the validation set (:1485-1492)
+            train_part, val_part = (0, n_local), (0, n_val_local)
+        else:
+            if parts is None:
+                parts = self._split(n_local, self.training_validation_lengths, self.random_split, gen)
+            parts = [p if isinstance(p, tuple) or self.shuffle else p.to(dev) for p in parts]  # index plans live on the GPU
+            train_part, val_part = parts[0], parts[1]
+        Xn_train = self.training_normalized
+        Xn_val = self.validation_normalized if separate_val else self.training_normalized
+        n_tr, n_va = self._part_len(train_part), self._part_len(val_part)
+        bs = local_bs if local_bs > 0 else max(n_tr, n_va, 1)
         if self.engine is not None:
             self.engine.close()
-        nmax = max(bs, 1)
+        nmax = max(1, min(bs, max(n_tr, n_va)))
         self.engine = hip.Mlp(self.model_kind, dims, acts, max_batch=nmax, lag=self.lag(), latent_layer=latent,
-                              tica_reg=float(self.configuration.get("tica_regularization", 1e-6)), lr=float(opt["lr"]),
-                              betas=tuple(opt["betas"]), eps=float(opt["eps"]), weight_decay=float(opt["weight_decay"]), device=dev)
+                              tica_reg=float(self.configuration.get("tica_regularization", 1e-6)), dropout=drops, seed=seed, device=dev,
+                              **self._engine_optimizer_kwargs(opt_name, opt_kw))
         self.engine.set_linears(linears)
         if self.model_kind == "ae":
             self.engine.set_feature_range(self.features_norm_range)
@@ -786,48 +974,66 @@ class NonLinear(CVCalculator):
         self._grads_view = self.engine.grads_view()
         world = self.comm.world
         gb = lambda n: n * world  # equal shards: every rank runs the same batch sizes
+        steps_per_epoch = (n_tr + bs - 1) // bs   # len(train_loader)
+        sched = None
+        so = self._scheduler_options(steps_per_epoch)
+        if so is not None:
+            sched = _HostLRScheduler(so[0], so[1], so[2], opt_name, {k: v for k, v in opt_kw.items()}, self.engine)
         metrics: Dict[str, list] = {"train_loss": [], "valid_loss": [], "epoch": []}
-        best_score, best_state, last_state, last_score = float("inf"), None, None, None
+        if sched is not None:
+            metrics["lr"] = []
+        best_score, best_state, last_state = float("inf"), None, None
         es_best, wait = float("inf"), 0
+        last_valid = None
         for epoch in range(self.max_epochs):
             tb = self._batches(train_part, bs, dev)
             do_val = (epoch + 1) % self.check_val_every_n_epoch == 0
             vb = self._batches(val_part, bs, dev) if do_val else []
             self.engine.reset_log(len(tb) + len(vb))
             for b in tb:
-                self._step(self.model_kind, b, True, gb)
+                self._step(Xn_train, b, True, gb)
+                if sched is not None:
+                    sched.after_step()
             for b in vb:
-                self._step(self.model_kind, b, False, gb)
+                self._step(Xn_val, b, False, gb)
             rec = self.engine.read_log()   # the only host sync of the epoch
             if not np.all(np.isfinite(rec[:, 0])):
                 raise FloatingPointError("non-finite loss (ill-conditioned batch covariance?)")
             train_loss, _, _ = self._records_to_metrics(rec[:len(tb)])
-            if not do_val:
-                continue
-            valid_loss, eig, buffers = self._records_to_metrics(rec[len(tb):])
-            metrics["train_loss"].append(train_loss)
-            metrics["valid_loss"].append(valid_loss)
-            metrics["epoch"].append(epoch)
-            if eig is not None:
-                for i, v in enumerate(eig):
-                    metrics.setdefault(f"valid_eigval_{i + 1}", []).append(float(v))
-            if (epoch + 1) % self.save_check_every_n_epoch == 0:  # ModelCheckpoint(save_top_k=1, save_last=True)
-                state = {"linears": self.engine.get_linears(), "tica": buffers, "dims": dims, "acts": acts, "latent": latent}
-                last_state, last_score = state, valid_loss
-                if valid_loss < best_score:
-                    best_score, best_state = valid_loss, state
-            if valid_loss < es_best - self.early_stop_delta:  # EarlyStopping(monitor=valid_loss, mode=min)
-                es_best, wait = valid_loss, 0
-            else:
-                wait += 1
-                if wait >= self.early_stop_patience:
-                    break
+            stop = False
+            if do_val:
+                valid_loss, eig, buffers = self._records_to_metrics(rec[len(tb):])
+                last_valid = valid_loss
+                metrics["train_loss"].append(train_loss)
+                metrics["valid_loss"].append(valid_loss)
+                metrics["epoch"].append(epoch)
+                if sched is not None:
+                    metrics["lr"].append(sched.lr())
+                if eig is not None:
+                    for i, v in enumerate(eig):
+                        metrics.setdefault(f"valid_eigval_{i + 1}", []).append(float(v))
+                if (epoch + 1) % self.save_check_every_n_epoch == 0:  # ModelCheckpoint(save_top_k=1, save_last=True)
+                    state = {"linears": self.engine.get_linears(), "tica": buffers, "dims": dims, "acts": acts, "drops": drops, "latent": latent}
+                    last_state = state
+                    if valid_loss < best_score:
+                        best_score, best_state = valid_loss, state
+                if valid_loss < es_best - self.early_stop_delta:  # EarlyStopping(monitor=valid_loss, mode=min)
+                    es_best, wait = valid_loss, 0
+                else:
+                    wait += 1
+                    stop = wait >= self.early_stop_patience
+            if sched is not None:
+                sched.after_epoch(last_valid)
+            if stop:
+                break
         if metrics["valid_loss"] and min(metrics["valid_loss"]) > metrics["valid_loss"][0]:
             logger.warning(f"Try {try_num}: validation loss did not decrease during training.")
+        # _finalize_training (reference :1555-1642): "best" = the checkpoint with the lowest monitored loss and that
+        # loss; "last" = the last checkpoint written, scored with the FINAL validation loss of the run
         if self.model_to_save == "best" and best_state is not None:
             state, score = best_state, best_score
         elif last_state is not None:
-            state, score = last_state, last_score
+            state, score = last_state, metrics["valid_loss"][-1]
         else:
             logger.error("Training finished, but no valid model checkpoint was found.")
             return None
@@ -946,6 +1152,13 @@ class NonLinear(CVCalculator):
             os.path.join(self.sensitivity_output_folder, "sensitivity_analysis.csv"))
 
     # ---- persistence
+    def _export_dropout(self, cfg: Dict, drops: List[float]) -> List[Optional[float]]:
+        """Dropout entry per Linear of the exported module tree: mlcolvar adds a Dropout module wherever the
+        configured value is not None -- also for 0 (the bundled models carry Dropout(p=0))."""
+        n = len(drops)
+        given = self._fit_list((cfg or {}).get("dropout", [None] * (n - 1)), n - 1, "dropout") + [(cfg or {}).get("last_layer_dropout", None)]
+        return [None if g is None else float(d) for g, d in zip(given, drops)]
+
     def to_torch_module(self) -> torch.nn.Module:
         raise NotImplementedError
 
@@ -1004,21 +1217,29 @@ class AECalculator(NonLinear):
         self.cv_name = "ae"
 
     def layer_plan(self):
-        enc_act, _ = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        enc_act, enc_drop = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
         dec_cfg = self.decoder_config if self.decoder_config is not None else self.encoder_config
-        dec_act, _ = self._layer_options(dec_cfg, len(self.decoder_hidden_layers))
+        dec_act, dec_drop = self._layer_options(dec_cfg, len(self.decoder_hidden_layers))
         # the decoder output must cover the range of the normalised features (reference :1188-1207)
         if self.feats_norm_mode == "min_max_range1" and dec_act[-1] != "custom_sigmoid":
-            raise NotImplementedError("min_max_range1 needs a custom_sigmoid output layer, which the HIP engine does not implement")
-        if self.feats_norm_mode == "min_max_range2" and dec_act[-1] != "tanh":
-            logger.warning("Changing the last decoder activation to 'tanh' (features normalised to [-1, 1]).")
+            logger.warning(f"The last layer activation function of the decoder is set to {dec_act[-1]}, but the features are "
+                           "normalized using min max with range [0, 1]. Changing the activation function to 'sigmoid'.")
+            dec_act[-1] = "custom_sigmoid"
+        elif self.feats_norm_mode == "min_max_range2" and dec_act[-1] != "tanh":
+            logger.warning(f"The last layer activation function of the decoder is set to {dec_act[-1]}, but the features are "
+                           "normalized using min max with range [-1, 1]. Changing the activation function to 'tanh'.")
             dec_act[-1] = "tanh"
+        if dec_drop[-1]:
+            logger.warning("Dropout in the last layer of the decoder is not recommended.")
         enc = [self.num_features] + self.encoder_hidden_layers + [self.cv_dimension]
         dec = [self.cv_dimension] + self.decoder_hidden_layers + [self.num_features]
-        return enc + dec[1:], enc_act + dec_act, len(enc) - 1
+        return enc + dec[1:], enc_act + dec_act, enc_drop + dec_drop, len(enc) - 1
 
     def n_samples_local(self) -> int:
         return self.training_data.shape[0]
+
+    def n_val_samples_local(self) -> int:
+        return self.validation_data.shape[0]
 
     def _records_to_metrics(self, rec):
         w = rec[:, 1]
@@ -1028,8 +1249,10 @@ class AECalculator(NonLinear):
         st = self.cv
         L = st["latent"]
         ne = len(self.encoder_hidden_layers) + 1
-        enc = export.FeedForward(st["linears"][:L], st["acts"][:L], [0.0] * (ne - 1) + [None])
-        dec = export.FeedForward(st["linears"][L:], st["acts"][L:], [0.0] * (len(st["linears"]) - L - 1) + [None])
+        drops = st.get("drops") or [0.0] * len(st["linears"])
+        enc = export.FeedForward(st["linears"][:L], st["acts"][:L], self._export_dropout(self.encoder_config, drops[:L]))
+        dec_cfg = self.decoder_config if self.decoder_config is not None else self.encoder_config
+        dec = export.FeedForward(st["linears"][L:], st["acts"][L:], self._export_dropout(dec_cfg, drops[L:]))
         norm = export.Normalization(self.features_norm_mean, self.features_norm_range) if self.feats_norm_mode is not None else None
         post = export.Normalization(*st["post"]) if st.get("post") is not None else None
         return export.AutoEncoderCV(norm, enc, dec, post)
@@ -1055,12 +1278,15 @@ class DeepTICACalculator(NonLinear):
         return int(self.configuration.get("lag_time"))
 
     def layer_plan(self):
-        act, _ = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        act, drop = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
         dims = [self.num_features] + self.encoder_hidden_layers + [self.cv_dimension]
-        return dims, act, len(dims) - 1
+        return dims, act, drop, len(dims) - 1
 
     def n_samples_local(self) -> int:
         return self.training_data.shape[0] - self.lag()   # pairs (i, i+lag) inside this rank's block
+
+    def n_val_samples_local(self) -> int:
+        return self.validation_data.shape[0] - self.lag()  # create_timelagged_dataset(validation_data) (reference :2546-2553)
 
     def _records_to_metrics(self, rec):
         d = self.cv_dimension
@@ -1081,7 +1307,7 @@ class DeepTICACalculator(NonLinear):
     def to_torch_module(self):
         st = self.cv
         nl = len(st["linears"])
-        nn_ = export.FeedForward(st["linears"], st["acts"], [0.0] * (nl - 1) + [None])
+        nn_ = export.FeedForward(st["linears"], st["acts"], self._export_dropout(self.encoder_config, st.get("drops") or [0.0] * nl))
         norm = export.Normalization(self.features_norm_mean, self.features_norm_range) if self.feats_norm_mode is not None else None
         tica = export.TICA(st["tica"][1], st["tica"][0])
         post = export.Normalization(*st["post"]) if st.get("post") is not None else None

@@ -12,14 +12,34 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
+class Shifted_Softplus(torch.nn.Softplus):
+    """mlcolvar.core.nn.utils.Shifted_Softplus: softplus shifted to pass through the origin."""
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return torch.nn.functional.softplus(input, self.beta, self.threshold) - 0.6931471824645996
+
+
+class Custom_Sigmoid(torch.nn.Module):
+    """mlcolvar.core.nn.utils.Custom_Sigmoid: 1 / (1 + exp(-p x)), p = 3."""
+
+    def __init__(self, p: float = 3.0):
+        super().__init__()
+        self.p = p
+
+    def forward(self, input: torch.Tensor) -> torch.Tensor:
+        return 1 / (1 + torch.exp(-self.p * input))
+
+
 _ACT_MODULES = {
+    "shifted_softplus": lambda: Shifted_Softplus(),
+    "custom_sigmoid": lambda: Custom_Sigmoid(),
     "relu": lambda: torch.nn.ReLU(True),
     "elu": lambda: torch.nn.ELU(True),
     "tanh": lambda: torch.nn.Tanh(),
     "softplus": lambda: torch.nn.Softplus(),
     "leaky_relu": lambda: torch.nn.LeakyReLU(),
 }
-_ACT_FROM_NAME = {"ReLU": "relu", "ELU": "elu", "Tanh": "tanh", "Softplus": "softplus", "LeakyReLU": "leaky_relu"}
+_ACT_FROM_NAME = {"Shifted_Softplus": "shifted_softplus", "Custom_Sigmoid": "custom_sigmoid", "ReLU": "relu", "ELU": "elu", "Tanh": "tanh", "Softplus": "softplus", "LeakyReLU": "leaky_relu"}
 
 
 class Normalization(torch.nn.Module):

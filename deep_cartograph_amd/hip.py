@@ -149,6 +149,19 @@ def gemm(mode: str, A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Cm
 
 
+def gemm_tn_split(A: torch.Tensor, B: torch.Tensor, k_chunk: int, slab_cap: int) -> torch.Tensor:
+    """Split-K A[K,M]^T.B[K,N]: slabs [ceil(K / k_chunk), M, N]; raises when slab_cap slabs are too few."""
+    _require_gpu(A, B)
+    _check_matrix(A)
+    _check_matrix(B)
+    K, M = A.shape
+    N = B.shape[1]
+    slab = torch.full((slab_cap + 1, M, N), float("nan"), dtype=torch.float32, device=A.device)   # one guard slab behind the capacity
+    check(_lib.load().dcv_gemm_tn_split(_ptr(A), A.stride(0), _ptr(B), B.stride(0), _ptr(slab), slab_cap, M, N, K, int(k_chunk), _stream()),
+          "dcv_gemm_tn_split")
+    return slab
+
+
 # ------------------------------------------------------------------------------- arithmetic mode
 def set_gemm_mode(mode: str) -> None:
     """'split' (default): FP32-accurate split products on the BF16 matrix pipe; 'native': FP32-input MFMA."""
@@ -249,8 +262,10 @@ class Mlp:
     (out x in weight, out bias) tensors in and out."""
 
     def __init__(self, model: str, dims, acts, *, max_batch: int, lag: int = 0, tica_reg: float = 1e-6,
-                 latent_layer: Optional[int] = None, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 weight_decay: float = 0.0, device="cuda"):
+                 latent_layer: Optional[int] = None, lr: float = 1e-3, betas=(0.9, 0.999), eps: Optional[float] = None,
+                 weight_decay: float = 0.0, optimizer: str = "Adam", amsgrad: bool = False, momentum: float = 0.0,
+                 dampening: float = 0.0, nesterov: bool = False, alpha: float = 0.99, centered: bool = False,
+                 lr_decay: float = 0.0, initial_accumulator_value: float = 0.0, dropout=None, seed: int = 0, device="cuda"):
         import ctypes as C
 
         if not torch.cuda.is_available():
@@ -276,7 +291,21 @@ class Mlp:
         desc.lag = int(lag)
         desc.max_batch = int(max_batch)
         desc.tica_reg = float(tica_reg)
+        if eps is None:   # torch's default for the optimiser
+            eps = 1e-10 if optimizer == "Adagrad" else 1e-8
         desc.lr, desc.beta1, desc.beta2, desc.eps, desc.weight_decay = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
+        if optimizer not in _lib.OPTIMIZER:
+            raise DcvError(f"optimizer {optimizer!r} is not implemented by the HIP engine (have: {sorted(_lib.OPTIMIZER)})")
+        desc.optimizer = _lib.OPTIMIZER[optimizer]
+        desc.amsgrad, desc.nesterov, desc.centered = int(bool(amsgrad)), int(bool(nesterov)), int(bool(centered))
+        desc.momentum, desc.dampening, desc.alpha = float(momentum), float(dampening), float(alpha)
+        desc.lr_decay, desc.initial_accumulator_value = float(lr_decay), float(initial_accumulator_value)
+        self.dropout = [float(p or 0.0) for p in (dropout if dropout is not None else [0.0] * L)]
+        if len(self.dropout) != L:
+            raise DcvError("one dropout probability per Linear layer expected")
+        for i, p in enumerate(self.dropout):
+            desc.dropout[i] = p
+        desc.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         h = C.c_void_p()
         check(self.lib.dcv_mlp_create(C.byref(desc), C.byref(h)), "dcv_mlp_create")
         self.h = h
@@ -351,6 +380,19 @@ class Mlp:
     def set_lr(self, lr: float):
         check(self.lib.dcv_mlp_set_lr(self.h, float(lr)), "dcv_mlp_set_lr")
 
+    def set_momentum(self, value: float):
+        """beta1 (Adam family) / momentum (SGD, RMSprop) of the following updates (cycled by OneCycleLR)."""
+        check(self.lib.dcv_mlp_set_momentum(self.h, float(value)), "dcv_mlp_set_momentum")
+
+    def dropout_step(self) -> int:
+        return int(self.lib.dcv_mlp_dropout_step(self.h))
+
+    def dropout_mask(self, layer: int, step: int, rows: int) -> torch.Tensor:
+        """keep / (1 - p) multipliers of the dropout behind Linear `layer` in training step `step` (test hook)."""
+        out = torch.empty(rows, self.dims[layer + 1], dtype=torch.float32, device=self.device)
+        check(self.lib.dcv_mlp_dropout_mask(self.h, int(layer), int(step), int(rows), _ptr(out), _stream()), "dcv_mlp_dropout_mask")
+        return out
+
     def set_row_sharing(self, enable: bool):
         """Deep-TICA contiguous batches: share the rows of the two halves (default) or not."""
         check(self.lib.dcv_mlp_set_row_sharing(self.h, 1 if enable else 0), "dcv_mlp_set_row_sharing")
@@ -367,9 +409,9 @@ class Mlp:
             raise DcvError("batch indices must be a contiguous int64 device tensor")
         return _ptr(Xn), Xn.stride(0), _ptr(idx), int(row0), int(batch)
 
-    def forward(self, Xn, idx=None, row0=0, batch=None):
+    def forward(self, Xn, idx=None, row0=0, batch=None, train=True):
         batch = int(batch if batch is not None else idx.numel())
-        check(self.lib.dcv_mlp_forward(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_forward")
+        check(self.lib.dcv_mlp_forward(self.h, *self._args(Xn, idx, row0, batch), 1 if train else 0, _stream()), "dcv_mlp_forward")
 
     def backward(self, Xn, idx=None, row0=0, batch=None, global_batch=None, train=True):
         batch = int(batch if batch is not None else idx.numel())

@@ -73,15 +73,19 @@ def train_colvars(configuration: Dict, train_colvars_paths: Union[str, List[str]
             continue
         df["traj_label"] = calc.training_data_labels
         paths = []
+        # under torch.distributed every rank holds the projection of all frames (run() gathers it): rank 0 writes
+        writer = calc.comm.rank == 0
         for i, name in enumerate(trajectory_names):
             traj_folder = os.path.join(cv_folder, "traj_data", name)
-            os.makedirs(traj_folder, exist_ok=True)
-            topology = train_topologies[i] if train_topologies else None
-            calc.write_plumed_files(topology, os.path.join(traj_folder, "plumed_inputs"), waypoint_structures)
-            df_i = df[df["traj_label"] == i].drop("traj_label", axis=1)
             p = os.path.join(traj_folder, "projected_trajectory.csv")
-            df_i.to_csv(p, index=False, float_format="%.4f")
+            if writer:
+                os.makedirs(traj_folder, exist_ok=True)
+                topology = train_topologies[i] if train_topologies else None
+                calc.write_plumed_files(topology, os.path.join(traj_folder, "plumed_inputs"), waypoint_structures)
+                df_i = df[df["traj_label"] == i].drop("traj_label", axis=1)
+                df_i.to_csv(p, index=False, float_format="%.4f")
             paths.append(p)
+        calc.comm.barrier()
         output_paths[cv_name] = paths
     logger.info("Elapsed time (Train colvars): %s", time.strftime("%H h %M min %S s", time.gmtime(time.time() - t0)))
     return output_paths

@@ -38,7 +38,7 @@ extern "C" {
 #define DCV_ENOMEM (-3)  /* workspace too small / allocation failed */
 #define DCV_ESTATE (-4)  /* call order violated */
 
-#define DCV_ABI_VERSION 1
+#define DCV_ABI_VERSION 2
 
 int dcv_abi_version(void);
 const char* dcv_last_error(void);
@@ -120,7 +120,18 @@ int dcv_project_linear(const float* X_d, int64_t n, int32_t F, int64_t ld,
 #define DCV_ACT_TANH 3
 #define DCV_ACT_ELU 4
 #define DCV_ACT_SOFTPLUS 5
+#define DCV_ACT_SHIFTED_SOFTPLUS 6 /* mlcolvar Shifted_Softplus: softplus(z) - softplus(0) */
+#define DCV_ACT_CUSTOM_SIGMOID 7   /* mlcolvar Custom_Sigmoid: 1 / (1 + exp(-3 z)); forced on the decoder output for
+                                      min_max_range1 features, cv_calculator.py:1193-1198 */
 #define DCV_MAX_LAYERS 16
+
+/* torch.optim.<name> as selected by optimizer.name of the training configuration (cv_calculator.py:1377-1380,
+ * model.optimizer_name :1511); single-tensor CPU arithmetic of torch 2.x, float32 state. */
+#define DCV_OPT_ADAM 0     /* lr, beta1, beta2, eps, weight_decay (L2 into the gradient), amsgrad */
+#define DCV_OPT_ADAMW 1    /* decoupled weight decay: p *= 1 - lr * weight_decay */
+#define DCV_OPT_SGD 2      /* lr, momentum, dampening, nesterov, weight_decay */
+#define DCV_OPT_RMSPROP 3  /* lr, alpha, eps, weight_decay, momentum, centered */
+#define DCV_OPT_ADAGRAD 4  /* lr, lr_decay, eps, weight_decay, initial_accumulator_value */
 
 #define DCV_MODEL_DEEPTICA 1 /* loss = -sum(eig^2) of the batch TICA of nn(x_t), nn(x_lag) */
 #define DCV_MODEL_AE 2       /* loss = mean(((dec(enc(xn)) - xn) * range)^2) */
@@ -135,8 +146,19 @@ typedef struct dcv_mlp_desc {
     int32_t lag;                        /* Deep-TICA pair offset in rows */
     int32_t max_batch;                  /* largest number of samples (pairs / frames) per step */
     double tica_reg;                    /* Deep-TICA: C0 + reg*I */
-    /* Adam (torch.optim.Adam semantics, cv_calculator.py:1377-1380) */
+    /* optimiser (torch.optim semantics, cv_calculator.py:1377-1380); fields a given optimiser does not have are ignored */
     double lr, beta1, beta2, eps, weight_decay;
+    int32_t optimizer;                  /* DCV_OPT_* */
+    int32_t amsgrad;                    /* Adam / AdamW */
+    int32_t nesterov;                   /* SGD */
+    int32_t centered;                   /* RMSprop */
+    double momentum, dampening;         /* SGD, RMSprop (momentum) */
+    double alpha;                       /* RMSprop smoothing constant */
+    double lr_decay, initial_accumulator_value; /* Adagrad */
+    /* torch.nn.Dropout(p) behind the activation of each Linear (mlcolvar FeedForward order: Linear, activation,
+     * dropout), active in training steps only; 0 = none.  Masks come from a counter-based generator keyed by `seed`. */
+    float dropout[DCV_MAX_LAYERS];
+    uint64_t seed;
 } dcv_mlp_desc;
 
 typedef struct dcv_mlp dcv_mlp; /* opaque; owns parameters, optimiser state and workspaces */
@@ -155,6 +177,9 @@ float* dcv_mlp_grads(dcv_mlp* m);
 int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* stream);
 int dcv_mlp_get_params(dcv_mlp* m, float* params_h, void* stream);
 int dcv_mlp_set_lr(dcv_mlp* m, double lr);
+/* beta1 (Adam / AdamW) or momentum (SGD / RMSprop): what torch's OneCycleLR / CyclicLR cycle next to the
+ * learning rate (cv_calculator.py:1228-1273 -> lr_scheduler). */
+int dcv_mlp_set_momentum(dcv_mlp* m, double value);
 /* Deep-TICA, contiguous batches (idx_d == NULL, 1 <= lag <= batch): x_lag of sample i is x_t of sample
  * i + lag, so by default the network is evaluated once on the batch + lag rows both halves share
  * (identical outputs, about half the matrix work; the gradient of a shared row is the sum of its two
@@ -170,7 +195,8 @@ int dcv_mlp_set_feature_range(dcv_mlp* m, const float* range_h, void* stream);
  * batch + lag - 1 must exist).
  * `global_batch` is the number of samples over ALL ranks (= batch on one GPU).
  *
- *   dcv_mlp_forward   forward pass; Deep-TICA: leaves the batch statistics
+ *   dcv_mlp_forward   forward pass (train != 0: dropout active, as in model.train(); 0: model.eval());
+ *                     Deep-TICA: leaves the batch statistics
  *                     [sum f_t (d) | sum f_lag (d) | sum f_t f_t^T (d*d) | sum f_t f_lag^T (d*d)]
  *                     as float64 in dcv_mlp_stats() (all-reduce SUM across ranks);
  *                     AE: leaves [sum of squared errors] there.
@@ -178,10 +204,10 @@ int dcv_mlp_set_feature_range(dcv_mlp* m, const float* range_h, void* stream);
  *                     (already scaled for the global batch; all-reduce SUM across ranks).
  *                     Appends one record to the metrics log (see dcv_mlp_read_log).
  *                     train = 0: evaluation only (loss logged, no gradients).
- *   dcv_mlp_apply     Adam update from dcv_mlp_grads().
+ *   dcv_mlp_apply     optimiser update from dcv_mlp_grads().
  */
 int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
-                    int32_t batch, void* stream);
+                    int32_t batch, int32_t train, void* stream);
 double* dcv_mlp_stats(dcv_mlp* m);
 int32_t dcv_mlp_stats_len(const dcv_mlp* m);
 int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
@@ -193,6 +219,13 @@ int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t*
 /* Convenience for one GPU: forward + backward(train=0). */
 int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
                       int32_t batch, void* stream);
+
+/* Test hook: keep / (1 - p) multipliers (0 or 1 / (1 - p)) that the dropout behind Linear `layer` applies to
+ * rows [0, rows) of the batch matrix in training step number `step` (0-based count of training forwards since
+ * creation / dcv_mlp_set_params); out_d is rows x dims[layer + 1] floats.  Lets the parity tests hand the oracle
+ * the very masks the engine used.  dcv_mlp_dropout_step returns the number of training forwards so far. */
+int dcv_mlp_dropout_mask(dcv_mlp* m, int32_t layer, int64_t step, int64_t rows, float* out_d, void* stream);
+int64_t dcv_mlp_dropout_step(const dcv_mlp* m);
 
 /* Metrics log: one record of dcv_mlp_log_width() float64 per backward call since the last
  * reset, kept on the device (no host sync inside an epoch).  Record layout:
@@ -300,6 +333,11 @@ int dcv_nearest_point(const double* train_d, int64_t n_train, const double* sup_
  * parity tests can exercise every operand form / tile shape / ragged edge directly. */
 int dcv_gemm_f32(int32_t mode, const float* A_d, int64_t lda, const float* B_d, int64_t ldb, float* C_d,
                  int64_t ldc, int64_t M, int64_t N, int64_t K, void* stream);
+/* Split-K form of mode 2 as the weight-gradient / covariance paths use it: the K rows are cut into chunks of
+ * k_chunk rows, chunk z writes its partial product to slab_d[z] (M x N floats each).  slab_cap is the number of
+ * slabs the buffer holds; a launch that needs more returns DCV_ENOMEM without touching memory. */
+int dcv_gemm_tn_split(const float* A_d, int64_t lda, const float* B_d, int64_t ldb, float* slab_d, int64_t slab_cap,
+                      int64_t M, int64_t N, int64_t K, int64_t k_chunk, void* stream);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,46 @@ import torch
 
 from .linear import cholesky_eigh, correlation_matrix
 
+class ShiftedSoftplus(torch.nn.Softplus):
+    """mlcolvar Shifted_Softplus [from knowledge of mlcolvar 1.2.2, core/nn/utils.py]: softplus(x) - softplus(0)."""
+
+    def forward(self, x):
+        sp0 = torch.nn.functional.softplus(torch.zeros(1), self.beta, self.threshold).item()
+        return torch.nn.functional.softplus(x, self.beta, self.threshold) - sp0
+
+
+class CustomSigmoid(torch.nn.Module):
+    """mlcolvar Custom_Sigmoid [from knowledge]: 1 / (1 + exp(-p x)), p = 3."""
+
+    def __init__(self, p=3):
+        super().__init__()
+        self.p = p
+
+    def forward(self, x):
+        return 1 / (1 + torch.exp(-self.p * x))
+
+
+class MaskedDropout(torch.nn.Module):
+    """torch.nn.Dropout whose keep / (1 - p) multipliers can be injected (tests hand it the masks the HIP engine
+    drew, since the reference's CPU generator stream cannot be reproduced on the device): `queue` holds one
+    multiplier tensor per forward call in training mode; empty queue -> ordinary torch dropout."""
+
+    def __init__(self, p):
+        super().__init__()
+        self.p = float(p)
+        self.queue = []
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        if self.queue:
+            return x * self.queue.pop(0)
+        return torch.nn.functional.dropout(x, self.p, True)
+
+
 ACTIVATIONS = {
+    "shifted_softplus": lambda: ShiftedSoftplus(),
+    "custom_sigmoid": lambda: CustomSigmoid(),
     "relu": lambda: torch.nn.ReLU(True),
     "elu": lambda: torch.nn.ELU(True),
     "tanh": lambda: torch.nn.Tanh(),
@@ -42,7 +81,7 @@ def feed_forward(layers: Sequence[int], activation: Sequence, dropout: Optional[
         if ACTIVATIONS[act] is not None:
             mods.append(ACTIVATIONS[act]())
         if dropout[i] is not None:
-            mods.append(torch.nn.Dropout(p=dropout[i]))
+            mods.append(MaskedDropout(p=dropout[i]))
     return torch.nn.Sequential(*mods)
 
 
@@ -186,11 +225,12 @@ def batches(idx: torch.Tensor, batch_size: int, shuffle: bool):
 
 
 def closest_power_of_two(n: int) -> int:
-    """modules/common/common.py:645-666 -- largest power of two <= n."""
-    p = 1
-    while p * 2 <= n:
-        p *= 2
-    return p
+    """modules/common/common.py:645-666 -- 2**floor(log2 n), halved when n is itself a power of two
+    (strictly below n); n = 1 (reference: 0.5) is clamped to 1."""
+    if n <= 1:
+        return 1
+    p = 2 ** math.floor(math.log2(n))
+    return p // 2 if p == n else p
 
 
 def clamp_batch_size(batch_size: int, n_total: int, train_frac: float) -> int:
@@ -206,82 +246,120 @@ def clamp_batch_size(batch_size: int, n_total: int, train_frac: float) -> int:
 def train(model, data: dict, *, seed_try: int, lengths=(0.8, 0.2), batch_size=32, shuffle=False,
           random_split=True, max_epochs=100, check_val_every_n_epoch=1, save_check_every_n_epoch=1,
           patience=20, min_delta=1e-5, optimizer="Adam", opt_kwargs=None, model_to_save="best",
-          build_model=None):
+          build_model=None, val_data: Optional[dict] = None, scheduler: Optional[dict] = None):
     """One training try of NonLinear.train (cv_calculator.py:1478-1539) without lightning.
 
     ``data``: {'data': X} for AE or {'data': x_t, 'data_lag': x_lag} for Deep-TICA (CPU f32).
-    RNG order (Appendix A.6, no LR scheduler): manual_seed(seed_try) -> model construction
-    (``build_model()``) -> randperm for the split.  Pass ``model=None, build_model=fn``
-    to have construction happen at the right point of the RNG stream.
+    ``val_data``: the same for a separately supplied validation set -- then the whole of ``data`` is
+    trained on and nothing is split (cv_calculator.py:1485-1492).
+    ``scheduler``: {'name', 'kwargs', 'config': {'interval', 'frequency', 'monitor'}} after
+    adjust_lr_scheduler (:1228-1273); stepped as lightning does (interval 'step': after every optimiser
+    step; 'epoch': at the end of every epoch, ReduceLROnPlateau with the latest valid_loss).
+    RNG order (Appendix A.6): manual_seed(seed_try) -> model construction (``build_model()``) -> randperm
+    for the split; with a scheduler and no separate validation set the split comes first (:1503 vs :1507).
+    Pass ``model=None, build_model=fn`` to have construction happen at the right point of the RNG stream.
     Returns dict(model, metrics, score, split)."""
     import copy
 
     opt_kwargs = dict(opt_kwargs or {"lr": 1e-3})
     gen = torch.manual_seed(seed_try)
+    n = data["data"].shape[0]
+    split = None
+    if scheduler is not None and val_data is None:
+        split = split_indices(n, lengths, random_split, gen)
     if model is None:
         model = build_model()
-    n = data["data"].shape[0]
-    train_idx, val_idx = split_indices(n, lengths, random_split, gen)
+    if val_data is not None:
+        train_idx, val_idx = torch.arange(n), torch.arange(val_data["data"].shape[0])
+    else:
+        train_idx, val_idx = split if split is not None else split_indices(n, lengths, random_split, gen)
+        val_data = data
     opt = getattr(torch.optim, optimizer)(model.parameters(), **opt_kwargs)
     is_tica = "data_lag" in data
+    sched, s_interval, s_freq, s_count = None, "epoch", 1, 0
+    if scheduler is not None:
+        sched = getattr(torch.optim.lr_scheduler, scheduler["name"])(opt, **scheduler.get("kwargs", {}))
+        s_interval = scheduler.get("config", {}).get("interval", "epoch")
+        s_freq = max(1, int(scheduler.get("config", {}).get("frequency", 1)))
+    plateau = isinstance(sched, torch.optim.lr_scheduler.ReduceLROnPlateau)
 
-    def run(idx):
+    def sched_step(metric=None):
+        nonlocal s_count
+        s_count += 1
+        if s_count % s_freq:
+            return
+        if plateau:
+            if metric is None:
+                raise ValueError("ReduceLROnPlateau conditioned on a metric which is not available yet")
+            sched.step(metric)
+        else:
+            sched.step()
+
+    def run(src, idx):
         if is_tica:
-            return model.step(data["data"][idx], data["data_lag"][idx])
-        return model.step(data["data"][idx])
+            return model.step(src["data"][idx], src["data_lag"][idx])
+        return model.step(src["data"][idx])
 
     metrics = {"train_loss": [], "valid_loss": [], "epoch": []}
     best_score, best_state, wait = float("inf"), None, 0
     es_best = float("inf")
     last_state, last_score = None, None
+    last_valid = None
     for epoch in range(max_epochs):
         model.train()
         tot, cnt = 0.0, 0
         for b in batches(train_idx, batch_size, shuffle):
             opt.zero_grad()
-            loss, _ = run(b)
+            loss, _ = run(data, b)
             loss.backward()
             opt.step()
+            if sched is not None and s_interval == "step":
+                sched_step()
             tot += float(loss.detach()) * len(b)
             cnt += len(b)
         train_loss = tot / cnt
-        if (epoch + 1) % check_val_every_n_epoch != 0:
-            continue
-        model.eval()
-        vt, vc, eig = 0.0, 0, None
-        with torch.no_grad():
-            for b in batches(val_idx, batch_size, shuffle):
-                loss, ev = run(b)
-                vt += float(loss) * len(b)
-                vc += len(b)
-                if ev is not None:
-                    eig = (ev * len(b)) if eig is None else eig + ev * len(b)
-        valid_loss = vt / vc
-        metrics["train_loss"].append(train_loss)
-        metrics["valid_loss"].append(valid_loss)
-        metrics["epoch"].append(epoch)
-        if eig is not None:
-            for i, v in enumerate((eig / vc).tolist()):
-                metrics.setdefault(f"valid_eigval_{i + 1}", []).append(v)
-        # ModelCheckpoint (save_top_k=1, save_last=True, every_n_epochs)
-        if (epoch + 1) % save_check_every_n_epoch == 0:
-            last_state, last_score = copy.deepcopy(model.state_dict()), valid_loss
-            if valid_loss < best_score:
-                best_score, best_state = valid_loss, copy.deepcopy(model.state_dict())
-        # EarlyStopping(monitor=valid_loss, mode=min)
-        if valid_loss < es_best - min_delta:
-            es_best, wait = valid_loss, 0
-        else:
-            wait += 1
-            if wait >= patience:
-                break
+        stop = False
+        if (epoch + 1) % check_val_every_n_epoch == 0:
+            model.eval()
+            vt, vc, eig = 0.0, 0, None
+            with torch.no_grad():
+                for b in batches(val_idx, batch_size, shuffle):
+                    loss, ev = run(val_data, b)
+                    vt += float(loss) * len(b)
+                    vc += len(b)
+                    if ev is not None:
+                        eig = (ev * len(b)) if eig is None else eig + ev * len(b)
+            valid_loss = vt / vc
+            last_valid = valid_loss
+            metrics["train_loss"].append(train_loss)
+            metrics["valid_loss"].append(valid_loss)
+            metrics["epoch"].append(epoch)
+            if eig is not None:
+                for i, v in enumerate((eig / vc).tolist()):
+                    metrics.setdefault(f"valid_eigval_{i + 1}", []).append(v)
+            # ModelCheckpoint (save_top_k=1, save_last=True, every_n_epochs)
+            if (epoch + 1) % save_check_every_n_epoch == 0:
+                last_state, last_score = copy.deepcopy(model.state_dict()), valid_loss
+                if valid_loss < best_score:
+                    best_score, best_state = valid_loss, copy.deepcopy(model.state_dict())
+            # EarlyStopping(monitor=valid_loss, mode=min)
+            if valid_loss < es_best - min_delta:
+                es_best, wait = valid_loss, 0
+            else:
+                wait += 1
+                stop = wait >= patience
+        if sched is not None and s_interval == "epoch":
+            sched_step(last_valid)
+        if stop:
+            break
     if model_to_save == "best" and best_state is not None:
         model.load_state_dict(best_state)
         score = best_score
     else:
         if last_state is not None:
             model.load_state_dict(last_state)
-        score = last_score
+        # _finalize_training (cv_calculator.py:1566): last_score = metrics['valid_loss'][-1], the FINAL validation loss
+        score = metrics["valid_loss"][-1] if metrics["valid_loss"] else last_score
     model.eval()
     return {"model": model, "metrics": metrics, "score": score, "split": (train_idx, val_idx)}
 

@@ -154,42 +154,69 @@ def test_tica_htica_pca_synthetic_1e5(tmp_path):
         assert err < 1e-5, (cv, err)
 
 
-LENGTHS = [0.785, 0.215]   # 163 pairs -> 128 / 35: two full training batches of 64, no near-singular 3-pair tail batch
+REF_TRAINING = json.loads(json.dumps(TEST_COMMON["training"]))
+REF_TRAINING["general"]["max_epochs"] = 1000     # the reference's own test configuration (tests/test_train_colvars.py:14-85)
 
 
-def _oracle_deeptica(X, m, r, seed, cfg):
-    g = cfg["training"]["general"]
-    data = {"data": torch.from_numpy(X[:-1]), "data_lag": torch.from_numpy(X[1:])}
-    bs = onn.clamp_batch_size(g["batch_size"], 163, LENGTHS[0])
-    res = onn.train(None, data, seed_try=seed, lengths=LENGTHS, batch_size=bs, shuffle=False, random_split=True, max_epochs=g["max_epochs"],
-                    check_val_every_n_epoch=1, save_check_every_n_epoch=1, patience=20, min_delta=1e-5, opt_kwargs={"lr": 1e-3},
-                    model_to_save="last",
-                    build_model=lambda: onn.DeepTICAModel([54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], m, r, 1e-6))
-    onn.finalize_postprocessing(res["model"], torch.from_numpy(X[:-1]))
+def _oracle_reference_config(kind, X, m, r):
+    """oracle.nn.train with the reference's test configuration: seed 42 + try 1, lengths [0.8, 0.2], batch 256 -> 128
+    (a 128 + 3 tail batch for Deep-TICA's 131 training pairs), max_epochs 1000, patience 20, model_to_save 'last'."""
+    kw = dict(seed_try=43, lengths=[0.8, 0.2], batch_size=onn.clamp_batch_size(256, 164, 0.8), shuffle=False, random_split=True,
+              max_epochs=1000, check_val_every_n_epoch=1, save_check_every_n_epoch=1, patience=20, min_delta=1e-5,
+              opt_kwargs={"lr": 1e-3, "weight_decay": 0}, model_to_save="last")
+    Xt = torch.from_numpy(X)
+    if kind == "deep_tica":
+        res = onn.train(None, {"data": Xt[:-1], "data_lag": Xt[1:]}, build_model=lambda: onn.DeepTICAModel(
+            [54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], m, r, 1e-6), **kw)
+        onn.finalize_postprocessing(res["model"], Xt[:-1])
+    else:
+        res = onn.train(None, {"data": Xt}, build_model=lambda: onn.AEModel(
+            [54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], [2, 4, 8, 54], ["leaky_relu", "leaky_relu", None],
+            [0.0, 0.0, None], m, r), **kw)
+        onn.finalize_postprocessing(res["model"], Xt)
     return res
 
 
-def test_deep_tica_calculator_vs_oracle(features, tmp_path):
+def test_deep_tica_calculator_reference_config(features, golden_nn, golden_proj, tmp_path):
+    """The HIP calculator on the reference's own test configuration against the weights / buffers of the reference's
+    bundled deep_tica_model.zip (tests/golden/nn_models.npz) and its golden CSV.  The oracle reproduces that fixture
+    (tests/test_oracle_golden.py::test_training_reproduces_reference_models), so the whole loop is pinned: DictLoader
+    order, the 3-pair tail batch, Adam, early stopping, the 'last' checkpoint."""
     X, names = features
-    training = json.loads(json.dumps(TEST_COMMON["training"]))
-    training["general"]["lengths"] = LENGTHS
-    calc = make_calc("deep_tica", tmp_path, training=training)
+    g = golden_nn
+    calc = make_calc("deep_tica", tmp_path, training=REF_TRAINING)
     calc.set_training_matrix(X.copy(), names)
     df = calc.run(2)
     assert df is not None and list(df.columns) == ["DeepTIC 1", "DeepTIC 2"]
-    assert calc.batch_size == 64   # 256 >= int(163 * 0.785) = 127 -> closest lower power of two
-    m, r = calc.features_norm_mean, calc.features_norm_range
-    res = _oracle_deeptica(X, m.astype(np.float32), r.astype(np.float32), 43, TEST_COMMON)
-    ref = res["model"]
-    np.testing.assert_allclose(calc.metrics["valid_loss"], res["metrics"]["valid_loss"], rtol=5e-3, atol=5e-4)
-    np.testing.assert_allclose(calc.metrics["train_loss"], res["metrics"]["train_loss"], rtol=5e-3, atol=5e-4)
-    lins = [mod for mod in ref.nn if isinstance(mod, torch.nn.Linear)]
-    for l, ((w, b), lin) in enumerate(zip(calc.cv["linears"], lins)):
-        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=2e-3)
+    assert calc.batch_size == 128   # 256 >= int(164 * 0.8) = 131 -> power of two below it
+    m, r = calc.features_norm_mean.astype(np.float32), calc.features_norm_range.astype(np.float32)
+    res = _oracle_reference_config("deep_tica", X, m, r)
+    assert len(calc.metrics["epoch"]) == len(res["metrics"]["epoch"]) == 21    # same early-stopping epoch as the reference run
+    np.testing.assert_allclose(calc.metrics["valid_loss"], res["metrics"]["valid_loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(calc.metrics["train_loss"], res["metrics"]["train_loss"], rtol=2e-4, atol=2e-5)
+    dev_w = max(np.max(np.abs(w - g[f"deep_tica.param.nn.nn.{i}.weight"])) for (w, _), i in zip(calc.cv["linears"], (0, 3, 6)))
+    dev_b = max(np.max(np.abs(b - g[f"deep_tica.param.nn.nn.{i}.bias"])) for (_, b), i in zip(calc.cv["linears"][:2], (0, 3)))
+    print(f"deep_tica vs reference fixture: max|dW| = {dev_w:.2e}, max|db hidden| = {dev_b:.2e}")
+    assert dev_w < 5e-5 and dev_b < 2e-4
+    # The last bias has an identically zero gradient in exact arithmetic (the batch TICA removes the mean): Adam turns its
+    # rounding noise into +-lr steps, in the reference as anywhere (the oracle differs from the fixture by 4e-3 there).
+    # What the model uses is bias - tica.mean, and that is pinned:
+    tmean, tevecs = calc.cv["tica"]
+    off = (calc.cv["linears"][2][1] - tmean) - (g["deep_tica.param.nn.nn.6.bias"] - g["deep_tica.buffer.tica.mean"])
+    assert np.max(np.abs(off)) < 5e-5
+    # The exported TICA is that of the 32 validation pairs of the last epoch: it magnifies weight noise ~40x (the oracle,
+    # 6e-6 from the fixture's weights, is 2e-4 off in the eigenvectors and 5e-4 in the CV).  Stated tolerances: 1e-3
+    # against the fixture (torch 2.1.2 numbers), and against the oracle run here.
+    np.testing.assert_allclose(tevecs, g["deep_tica.buffer.tica.evecs"], atol=1e-3)
     with torch.no_grad():
-        Y = ref(torch.from_numpy(X)).numpy()
-    # the CV itself (sign fixed by the TICA convention), stated tolerance 2e-2 of the [-1, 1] range after 40 epochs
-    assert np.max(np.abs(df.to_numpy() - Y)) < 2e-2
+        Yo = res["model"](torch.from_numpy(X)).numpy()
+    dev_cv = np.max(np.abs(df.to_numpy() - g["deep_tica.output"]))
+    dev_or = np.max(np.abs(df.to_numpy() - Yo))
+    lins_o = [mod for mod in res["model"].nn if isinstance(mod, torch.nn.Linear)]
+    dev_wo = max(np.max(np.abs(w - lin.weight.detach().numpy())) for (w, _), lin in zip(calc.cv["linears"], lins_o))
+    print(f"deep_tica CV: max|d| vs reference model output = {dev_cv:.2e}, vs oracle = {dev_or:.2e}; max|dW| vs oracle = {dev_wo:.2e}; "
+          f"identical '%.4f' entries vs golden CSV: {match_fraction(df.to_numpy(), golden_proj['deep_tica']):.3f}")
+    assert dev_cv < 1e-3 and dev_or < 1e-3 and dev_wo < 5e-5
     # exported TorchScript: reference tree, loads with plain torch.jit, reproduces the projection
     with zipfile.ZipFile(tmp_path / "deep_tica" / "model.zip") as z:
         assert sorted(z.namelist()) == ["model/cv_weights.pt", "model/features_labels.txt", "model/metadata.json"]
@@ -210,22 +237,31 @@ def test_deep_tica_calculator_vs_oracle(features, tmp_path):
     _check_sensitivity(tmp_path / "deep_tica", ts, X[:-1], names)
 
 
-def test_ae_calculator_vs_oracle(features, tmp_path):
+def test_ae_calculator_reference_config(features, golden_nn, golden_proj, tmp_path):
+    """AECalculator on the reference's test configuration against ae_model.zip's weights (544 epochs, 1088 Adam steps)."""
     X, names = features
-    calc = make_calc("ae", tmp_path)
+    g = golden_nn
+    calc = make_calc("ae", tmp_path, training=REF_TRAINING)
     calc.set_training_matrix(X.copy(), names)
     df = calc.run(2)
     assert df is not None and list(df.columns) == ["AE 1", "AE 2"]
     m, r = calc.features_norm_mean.astype(np.float32), calc.features_norm_range.astype(np.float32)
-    res = onn.train(None, {"data": torch.from_numpy(X)}, seed_try=43, batch_size=128, shuffle=False, random_split=True, max_epochs=40,
-                    opt_kwargs={"lr": 1e-3}, model_to_save="last",
-                    build_model=lambda: onn.AEModel([54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None],
-                                                    [2, 4, 8, 54], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], m, r))
-    np.testing.assert_allclose(calc.metrics["valid_loss"], res["metrics"]["valid_loss"], rtol=2e-3)
-    ref = onn.finalize_postprocessing(res["model"], torch.from_numpy(X))
-    with torch.no_grad():
-        Y = ref(torch.from_numpy(X)).numpy()
-    assert np.max(np.abs(df.to_numpy() - Y)) < 5e-3
+    res = _oracle_reference_config("ae", X, m, r)
+    n_ref = len(res["metrics"]["epoch"])
+    print(f"ae epochs: engine {len(calc.metrics['epoch'])}, oracle {n_ref}")
+    assert n_ref == 544
+    n = min(n_ref, len(calc.metrics["epoch"]))
+    np.testing.assert_allclose(calc.metrics["valid_loss"][:n], res["metrics"]["valid_loss"][:n], rtol=2e-4)
+    L = calc.cv["latent"]
+    dev = 0.0
+    for part, lins in (("encoder", calc.cv["linears"][:L]), ("decoder", calc.cv["linears"][L:])):
+        for (w, b), i in zip(lins, (0, 3, 6)):
+            dev = max(dev, np.max(np.abs(w - g[f"ae.param.{part}.nn.{i}.weight"])), np.max(np.abs(b - g[f"ae.param.{part}.nn.{i}.bias"])))
+    dev_cv = np.max(np.abs(df.to_numpy() - g["ae.output"]))
+    frac = match_fraction(df.to_numpy(), golden_proj["ae"])
+    print(f"ae vs reference fixture: max|d param| = {dev:.2e}; CV max|d| = {dev_cv:.2e}; identical '%.4f' entries: {frac:.3f}")
+    assert len(calc.metrics["epoch"]) == n_ref   # same early-stopping epoch as the reference run
+    assert dev < 2e-4 and dev_cv < 5e-4 and frac > 0.85
     with zipfile.ZipFile(tmp_path / "ae" / "model.zip") as z:
         ts = torch.jit.load(io.BytesIO(z.read("model/cv_weights.pt")))
     assert {n.split(".")[0] for n, _ in ts.named_parameters()} == {"encoder", "decoder"}

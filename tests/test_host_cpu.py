@@ -34,7 +34,7 @@ def test_merge_and_power_of_two(tmp_path):
     out = merge_configurations(common, {"t": {"y": {"z": 3}, "w": 4}, "b": 5})
     assert out == {"a": 1, "t": {"x": 1, "y": {"z": 3}, "w": 4}, "b": 5}
     assert common["t"]["y"]["z"] == 2
-    assert [closest_power_of_two(n) for n in (1, 2, 3, 130, 256, 257)] == [1, 2, 2, 128, 256, 256]
+    assert [closest_power_of_two(n) for n in (1, 2, 3, 130, 131, 256, 257)] == [1, 1, 2, 128, 128, 128, 256]
     cfg = validate_configuration({"cvs": ["tica"]}, TrainColvarsSchema, str(tmp_path))
     assert cfg["common"]["training"]["general"]["batch_size"] == 32
     assert os.path.exists(tmp_path / "configuration.yml")

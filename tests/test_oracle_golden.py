@@ -142,6 +142,67 @@ def test_ae_forward(features, golden_nn, golden_proj):
     np.testing.assert_array_equal(ol.csv_round4(g["ae.output"]), golden_proj["ae"])
 
 
+def _reference_test_training(kind, X, m, r):
+    """NonLinear.train of the reference's own test (tests/test_train_colvars.py:14-85): seed 42 + try 1, lengths
+    [0.8, 0.2], batch 256 -> 128, max_epochs 1000, patience 20, min_delta 1e-5, Adam lr 1e-3, model_to_save 'last'."""
+    kw = dict(seed_try=43, lengths=[0.8, 0.2], batch_size=onn.clamp_batch_size(256, 164, 0.8), shuffle=False, random_split=True,
+              max_epochs=1000, check_val_every_n_epoch=1, save_check_every_n_epoch=1, patience=20, min_delta=1e-5,
+              opt_kwargs={"lr": 1e-3, "weight_decay": 0}, model_to_save="last")
+    Xt = torch.from_numpy(X)
+    if kind == "ae":
+        return onn.train(None, {"data": Xt}, build_model=lambda: onn.AEModel(
+            [54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], [2, 4, 8, 54], ["leaky_relu", "leaky_relu", None],
+            [0.0, 0.0, None], m, r), **kw)
+    return onn.train(None, {"data": Xt[:-1], "data_lag": Xt[1:]}, build_model=lambda: onn.DeepTICAModel(
+        [54, 16, 8, 2], ["leaky_relu", "leaky_relu", None], [0.0, 0.0, None], m, r, 1e-6), **kw)
+
+
+def test_training_reproduces_reference_models(features, golden_nn, golden_proj):
+    """The training LOOP is pinned by the reference's fixtures: run on the reference's test configuration the oracle
+    lands on the weights inside the reference's bundled ae_model.zip (544 epochs, 1088 Adam steps) and
+    deep_tica_model.zip (21 epochs) -- DictLoader order, the 128 + 3 tail batch, Adam, early stopping and the 'last'
+    checkpoint included.  Tolerances: float32 noise between torch builds (the fixtures were written by torch 2.1.2)."""
+    X, _ = features
+    g = golden_nn
+    _, st, m, r, _ = _normalized(features)
+    m, r = m.astype(np.float32), r.astype(np.float32)
+    assert onn.clamp_batch_size(256, 164, 0.8) == 128
+    # ---- autoencoder
+    res = _reference_test_training("ae", X, m, r)
+    assert len(res["metrics"]["epoch"]) == 544
+    mod = res["model"]
+    for part in ("encoder", "decoder"):
+        sd = getattr(mod, part).state_dict()
+        for i in (0, 3, 6):
+            np.testing.assert_allclose(sd[f"{i}.weight"].numpy(), g[f"ae.param.{part}.nn.{i}.weight"], atol=5e-6)
+            np.testing.assert_allclose(sd[f"{i}.bias"].numpy(), g[f"ae.param.{part}.nn.{i}.bias"], atol=5e-6)
+    onn.finalize_postprocessing(mod, torch.from_numpy(X))
+    with torch.no_grad():
+        Y = mod(torch.from_numpy(X)).numpy()
+    np.testing.assert_allclose(Y, g["ae.output"], atol=2e-5)
+    assert np.mean(ol.csv_round4(Y) == golden_proj["ae"]) > 0.99
+    # ---- Deep-TICA
+    res = _reference_test_training("deep_tica", X, m, r)
+    assert len(res["metrics"]["epoch"]) == 21
+    mod = res["model"]
+    sd = mod.nn.state_dict()
+    for i in (0, 3, 6):
+        np.testing.assert_allclose(sd[f"{i}.weight"].numpy(), g[f"deep_tica.param.nn.nn.{i}.weight"], atol=2e-5)
+    for i in (0, 3):
+        np.testing.assert_allclose(sd[f"{i}.bias"].numpy(), g[f"deep_tica.param.nn.nn.{i}.bias"], atol=1e-4)
+    # the last bias is a pure offset the batch TICA removes: its exact gradient is zero, Adam turns the rounding noise
+    # into +-lr steps (4e-3 away from the fixture after 42 steps) and tica.mean follows it -- their difference is pinned
+    off = (sd["6.bias"].numpy() - mod.tica_mean.numpy()) - (g["deep_tica.param.nn.nn.6.bias"] - g["deep_tica.buffer.tica.mean"])
+    assert np.max(np.abs(off)) < 2e-5
+    np.testing.assert_allclose(mod.tica_evecs.numpy(), g["deep_tica.buffer.tica.evecs"], atol=5e-4)
+    onn.finalize_postprocessing(mod, torch.from_numpy(X[:-1]))
+    with torch.no_grad():
+        Y = mod(torch.from_numpy(X)).numpy()
+    # the exported TICA is that of the 32 validation pairs of the last epoch: it magnifies the 6e-6 weight noise to
+    # 2e-4 in the eigenvectors and 5e-4 in the CV (torch 2.1.2 fixture vs the torch installed here)
+    np.testing.assert_allclose(Y, g["deep_tica.output"], atol=1e-3)
+
+
 # ----------------------------------------------------------------------------- clustering
 def test_reference_cluster_goldens_reproduced(golden_cluster, golden_proj):
     """Appendix A.7: the reference module reproduces reference/traj_cluster/*.csv exactly."""

@@ -421,6 +421,9 @@ static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64
 #else
     using Big = CfgBigT<S>;
 #endif
+#ifdef DCV_FORCE_BIG   // diagnostic (tools/gemm_bench): every product takes the DCV_BIGCFG tile, whatever its extents
+    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+#endif
     if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
     if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
     if constexpr (MODE != kTN) {

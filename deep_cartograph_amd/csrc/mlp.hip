@@ -49,13 +49,14 @@ struct dcv_mlp {
     double momentum_rt;        // beta1 (Adam family) or momentum (SGD, RMSprop): dcv_mlp_set_momentum
     bool any_drop;             // some layer has dropout p > 0
     bool fwd_train;            // the last forward ran in training mode (dropout active): backward must agree
+    bool head_done;            // the last forward already ran the d x d loss head inside its statistics launch (one-GPU steps)
     int64_t drop_step;         // training forwards so far = step field of the next forward's dropout counters
     int64_t cur_step;          // step field of the last training forward
     float* dZ[2];
     int64_t ld_dz;
     double* stats;             // device
     int stats_len;
-    float* gradp;              // Deep-TICA: [mu d | Gu d*d | Gv d*d | c d]
+    double* gradp;             // Deep-TICA: [mu d | Gu d*d | Gv d*d | c d], float64 (see tica_dF_kernel)
     double* spart;             // stats partials
     int spart_blocks;
     double* log;
@@ -129,11 +130,95 @@ struct ReduceArgs {
     int L;
 };
 
+// torch.optim single-tensor updates (CPU code path of torch 2.x: _single_tensor_adam / _adamw / _sgd / _rmsprop /
+// _adagrad), fp32 state.  One thread per element; `s1`, `s2`, `s3` are the optimiser's state tensors.
+struct OptArgs {
+    int kind, flag;   // DCV_OPT_*; flag: amsgrad (Adam family), nesterov (SGD), centered (RMSprop)
+    int first;        // SGD: first step (momentum buffer := gradient)
+    float lr, b1, b2, eps, wd;
+    float c1, c2;     // Adam family: lr / (1 - b1^t), sqrt(1 - b2^t); Adagrad: c1 = lr / (1 + (t - 1) lr_decay)
+    // scalars torch forms in Python doubles and then hands to a float32 kernel: computed on the host in double and
+    // rounded once, exactly as there ((float)(1 - 0.999) is not 1.f - 0.999f)
+    float w1, w2;     // 1 - beta1 (Adam) / 1 - dampening (SGD) ; 1 - beta2 (Adam) / 1 - alpha (RMSprop)
+    float decay;      // AdamW: 1 - lr * weight_decay
+};
+__device__ __forceinline__ void opt_update(int64_t i, float gi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                           float* __restrict__ s3, const OptArgs& a) {
+    float pi = p[i];
+    switch (a.kind) {
+        case DCV_OPT_ADAM:
+        case DCV_OPT_ADAMW: {
+            if (a.kind == DCV_OPT_ADAMW) pi = pi * a.decay;                        // param.mul_(1 - lr * weight_decay)
+            else if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);                        // grad.add(param, alpha=weight_decay)
+            float mi = s1[i], vi = s2[i];
+            mi = mi + (gi - mi) * a.w1;                                           // exp_avg.lerp_(grad, 1 - beta1)
+            vi = vi * a.b2 + a.w2 * gi * gi;                                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+            float vden = vi;
+            if (a.flag) {                                                          // amsgrad: max_exp_avg_sq = max(., exp_avg_sq)
+                vden = fmaxf(s3[i], vi);
+                s3[i] = vden;
+            }
+            const float denom = sqrtf(vden) / a.c2 + a.eps;
+            s1[i] = mi;
+            s2[i] = vi;
+            p[i] = pi - a.c1 * (mi / denom);                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+            break;
+        }
+        case DCV_OPT_SGD: {
+            if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+            if (a.b1 != 0.f) {                                                     // b1 = momentum, w1 = 1 - dampening
+                float bi = a.first ? gi : s1[i] * a.b1 + a.w1 * gi;               // buf.mul_(momentum).add_(grad, alpha=1 - dampening)
+                s1[i] = bi;
+                gi = a.flag ? fmaf(a.b1, bi, gi) : bi;                            // nesterov: grad.add(buf, alpha=momentum)
+            }
+            p[i] = pi - a.lr * gi;
+            break;
+        }
+        case DCV_OPT_RMSPROP: {
+            if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+            float sq = s2[i] * a.b2 + a.w2 * gi * gi;                             // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
+            s2[i] = sq;
+            float avg;
+            if (a.flag) {                                                          // centered
+                float ga = s3[i];
+                ga = ga + (gi - ga) * a.w2;                                        // grad_avg.lerp_(grad, 1 - alpha)
+                s3[i] = ga;
+                avg = sqrtf(sq - ga * ga) + a.eps;                                 // addcmul(grad_avg, grad_avg, -1).sqrt_().add_(eps)
+            } else {
+                avg = sqrtf(sq) + a.eps;
+            }
+            if (a.b1 > 0.f) {                                                      // b1 = momentum
+                const float bi = s1[i] * a.b1 + gi / avg;                          // buf.mul_(momentum).addcdiv_(grad, avg)
+                s1[i] = bi;
+                p[i] = pi - a.lr * bi;
+            } else {
+                p[i] = pi - a.lr * (gi / avg);
+            }
+            break;
+        }
+        default: {   // DCV_OPT_ADAGRAD
+            if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+            const float su = s2[i] + gi * gi;                                      // state_sum.addcmul_(grad, grad, value=1)
+            s2[i] = su;
+            p[i] = pi - a.c1 * (gi / (sqrtf(su) + a.eps));                         // param.addcdiv_(grad, std, value=-clr)
+            break;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+                                                        float* __restrict__ s2, float* __restrict__ s3, int64_t n, OptArgs a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) opt_update(i, g[i], p, s1, s2, s3, a);
+}
+
 // grads[w] = sum_s slab[s][w] ; grads[b] = sum_blk bpart[blk][b].  A block covers 64 consecutive
 // elements; its 16 waves take the partials q = wave, wave + 16, ... (coalesced 256-byte reads)
 // and are combined in wave order: float64 accumulation, fixed order, deterministic.
 constexpr int kRedWaves = 16;
-__global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs a, float* __restrict__ grads, float scale) {
+// fuse != 0 (one-GPU training step, nothing to all-reduce in between): the thread that finishes a gradient element
+// applies the optimiser update to its parameter at once -- one launch less per step.
+__global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs a, float* __restrict__ grads, float scale, int fuse,
+                                                                      float* __restrict__ params, float* __restrict__ s1,
+                                                                      float* __restrict__ s2, float* __restrict__ s3, OptArgs oa) {
     __shared__ double s_red[kRedWaves][64];
     const int l = blockIdx.y;
     const ReduceDesc& d = a.l[l];
@@ -158,89 +243,11 @@ __global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs
 #pragma unroll
             for (int w = 0; w < kRedWaves; ++w) tot += s_red[w][lane];
             const float g = (float)(tot * (double)scale);
-            if (i < d.w_count) grads[d.w_off + i] = g;
-            else grads[d.b_off + (i - d.w_count)] = g;
+            const int64_t pidx = i < d.w_count ? d.w_off + i : d.b_off + (i - d.w_count);
+            grads[pidx] = g;
+            if (fuse) opt_update(pidx, g, params, s1, s2, s3, oa);
         }
         __syncthreads();
-    }
-}
-
-// torch.optim single-tensor updates (CPU code path of torch 2.x: _single_tensor_adam / _adamw / _sgd / _rmsprop /
-// _adagrad), fp32 state.  One thread per element; `s1`, `s2`, `s3` are the optimiser's state tensors.
-struct OptArgs {
-    int kind, flag;   // DCV_OPT_*; flag: amsgrad (Adam family), nesterov (SGD), centered (RMSprop)
-    int first;        // SGD: first step (momentum buffer := gradient)
-    float lr, b1, b2, eps, wd;
-    float c1, c2;     // Adam family: lr / (1 - b1^t), sqrt(1 - b2^t); Adagrad: c1 = lr / (1 + (t - 1) lr_decay)
-    // scalars torch forms in Python doubles and then hands to a float32 kernel: computed on the host in double and
-    // rounded once, exactly as there ((float)(1 - 0.999) is not 1.f - 0.999f)
-    float w1, w2;     // 1 - beta1 (Adam) / 1 - dampening (SGD) ; 1 - beta2 (Adam) / 1 - alpha (RMSprop)
-    float decay;      // AdamW: 1 - lr * weight_decay
-};
-__global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
-                                                        float* __restrict__ s2, float* __restrict__ s3, int64_t n, OptArgs a) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        float gi = g[i];
-        float pi = p[i];
-        switch (a.kind) {
-            case DCV_OPT_ADAM:
-            case DCV_OPT_ADAMW: {
-                if (a.kind == DCV_OPT_ADAMW) pi = pi * a.decay;                        // param.mul_(1 - lr * weight_decay)
-                else if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);                        // grad.add(param, alpha=weight_decay)
-                float mi = s1[i], vi = s2[i];
-                mi = mi + (gi - mi) * a.w1;                                           // exp_avg.lerp_(grad, 1 - beta1)
-                vi = vi * a.b2 + a.w2 * gi * gi;                                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-                float vden = vi;
-                if (a.flag) {                                                          // amsgrad: max_exp_avg_sq = max(., exp_avg_sq)
-                    vden = fmaxf(s3[i], vi);
-                    s3[i] = vden;
-                }
-                const float denom = sqrtf(vden) / a.c2 + a.eps;
-                s1[i] = mi;
-                s2[i] = vi;
-                p[i] = pi - a.c1 * (mi / denom);                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
-                break;
-            }
-            case DCV_OPT_SGD: {
-                if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-                if (a.b1 != 0.f) {                                                     // b1 = momentum, w1 = 1 - dampening
-                    float bi = a.first ? gi : s1[i] * a.b1 + a.w1 * gi;               // buf.mul_(momentum).add_(grad, alpha=1 - dampening)
-                    s1[i] = bi;
-                    gi = a.flag ? fmaf(a.b1, bi, gi) : bi;                            // nesterov: grad.add(buf, alpha=momentum)
-                }
-                p[i] = pi - a.lr * gi;
-                break;
-            }
-            case DCV_OPT_RMSPROP: {
-                if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-                float sq = s2[i] * a.b2 + a.w2 * gi * gi;                             // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
-                s2[i] = sq;
-                float avg;
-                if (a.flag) {                                                          // centered
-                    float ga = s3[i];
-                    ga = ga + (gi - ga) * a.w2;                                        // grad_avg.lerp_(grad, 1 - alpha)
-                    s3[i] = ga;
-                    avg = sqrtf(sq - ga * ga) + a.eps;                                 // addcmul(grad_avg, grad_avg, -1).sqrt_().add_(eps)
-                } else {
-                    avg = sqrtf(sq) + a.eps;
-                }
-                if (a.b1 > 0.f) {                                                      // b1 = momentum
-                    const float bi = s1[i] * a.b1 + gi / avg;                          // buf.mul_(momentum).addcdiv_(grad, avg)
-                    s1[i] = bi;
-                    p[i] = pi - a.lr * bi;
-                } else {
-                    p[i] = pi - a.lr * (gi / avg);
-                }
-                break;
-            }
-            default: {   // DCV_OPT_ADAGRAD
-                if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
-                const float su = s2[i] + gi * gi;                                      // state_sum.addcmul_(grad, grad, value=1)
-                s2[i] = su;
-                p[i] = pi - a.c1 * (gi / (sqrtf(su) + a.eps));                         // param.addcdiv_(grad, std, value=-clr)
-                break;
-            }
-        }
     }
 }
 
@@ -280,76 +287,6 @@ __global__ __launch_bounds__(256) void tica_stats_kernel(const float* __restrict
             for (int r = 0; r < nr; ++r) s += s_t[r * d + i] * s_l[r * d + j];
         }
         my[o] = s;
-    }
-}
-
-// The same statistics for D <= 4 outputs with every thread at work: a thread walks whole rows (its pair's
-// 2 D values, 2 D + 2 D^2 float64 accumulators in registers), waves combine by shuffles, the block through
-// LDS -- kFastStatRows pairs per block, so the second-stage sum sees 16 times fewer partials.
-constexpr int kFastStatRows = 2048;
-template <int D>
-__global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __restrict__ F, int64_t ld, int B, int lag_off,
-                                                              double* __restrict__ part, unsigned* __restrict__ ticket,
-                                                              double* __restrict__ out) {
-    constexpr int W = 2 * D + 2 * D * D;
-    __shared__ double red[4][W];
-    __shared__ unsigned s_last;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double acc[W];
-#pragma unroll
-    for (int o = 0; o < W; ++o) acc[o] = 0.0;
-    const int64_t r0 = (int64_t)blockIdx.x * kFastStatRows;
-    const int64_t r1 = r0 + kFastStatRows < B ? r0 + kFastStatRows : B;
-    for (int64_t r = r0 + t; r < r1; r += 256) {
-        double a[D], b[D];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            a[i] = (double)F[r * ld + i];
-            b[i] = (double)F[(r + lag_off) * ld + i];
-        }
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            acc[i] += a[i];
-            acc[D + i] += b[i];
-#pragma unroll
-            for (int j = 0; j < D; ++j) {
-                acc[2 * D + i * D + j] += a[i] * a[j];
-                acc[2 * D + D * D + i * D + j] += a[i] * b[j];
-            }
-        }
-    }
-#pragma unroll
-    for (int o = 0; o < W; ++o) {
-        double v = acc[o];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][o] = v;
-    }
-    __syncthreads();
-    if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
-    // the block that finishes last adds the partials up in block order (no second launch; same sums whichever
-    // block it is)
-    __threadfence();
-    __syncthreads();
-    if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-        __threadfence();
-        if (t < W) {
-            double s = 0.0;
-            for (unsigned b = 0; b < gridDim.x; ++b) s += part[(int64_t)b * W + t];
-            out[t] = s;
-        }
-        if (t == 0) *ticket = 0u;
-    }
-}
-typedef void (*tica_stats_fn_t)(const float*, int64_t, int, int, double*, unsigned*, double*);
-static tica_stats_fn_t tica_stats_rows_fn(int d) {
-    switch (d) {
-        case 1: return tica_stats_rows_kernel<1>;
-        case 2: return tica_stats_rows_kernel<2>;
-        case 3: return tica_stats_rows_kernel<3>;
-        case 4: return tica_stats_rows_kernel<4>;
-        default: return nullptr;
     }
 }
 
@@ -394,9 +331,8 @@ __global__ __launch_bounds__(64) void sum_partials_kernel(const double* __restri
 // turn (f_t - mu, f_lag - mu) into dL/df (see DESIGN.md "Deep-TICA gradient").  DT > 0 fixes the
 // dimension at compile time (everything in registers); DT == 0 is the generic d <= 16 form.
 template <int DT>
-__global__ void tica_grad_kernel(const double* __restrict__ stats, int d_rt, double Bg, double reg, float* __restrict__ gradp,
-                                 double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats, int d_rt, double Bg, double reg, double* __restrict__ gradp,
+                                               double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
     constexpr int DM = DT > 0 ? DT : kMaxTicaDim;
     const int d = DT > 0 ? DT : d_rt;
     double mu[DM], ml[DM];
@@ -497,14 +433,14 @@ __global__ void tica_grad_kernel(const double* __restrict__ stats, int d_rt, dou
                         if (k < d) s += K[i * DM + k] * A[k * DM + j];
                     T[i * DM + j] = s;
                 }
-        float* g_mu = gradp;
-        float* g_u = gradp + d;
-        float* g_v = g_u + d * d;
-        float* g_c = g_v + d * d;
+        double* g_mu = gradp;
+        double* g_u = gradp + d;
+        double* g_v = g_u + d * d;
+        double* g_c = g_v + d * d;
 #pragma unroll
         for (int i = 0; i < DM; ++i)
             if (i < d) {
-                g_mu[i] = (float)mu[i];
+                g_mu[i] = mu[i];
                 double cs = 0.0;
 #pragma unroll
                 for (int j = 0; j < DM; ++j)
@@ -514,11 +450,11 @@ __global__ void tica_grad_kernel(const double* __restrict__ stats, int d_rt, dou
                         for (int k = 0; k < DM; ++k)
                             if (k < d) g0 += K[i * DM + k] * T[k * DM + j];
                         const double Gt = -(T[i * DM + j] + T[j * DM + i]);  // -2 * sym(T)
-                        g_u[i * d + j] = (float)(4.0 * g0 / Bg);              // (2/B) G0, G0 = 2 K T
-                        g_v[i * d + j] = (float)(Gt / Bg);                    // (1/B) Gtau
+                        g_u[i * d + j] = 4.0 * g0 / Bg;                       // (2/B) G0, G0 = 2 K T
+                        g_v[i * d + j] = Gt / Bg;                             // (1/B) Gtau
                         cs += Gt * (ml[j] - mu[j]);
                     }
-                g_c[i] = (float)(-cs / Bg);
+                g_c[i] = -cs / Bg;
             }
     }
     const int slot = *log_count;
@@ -540,8 +476,14 @@ __global__ void tica_grad_kernel(const double* __restrict__ stats, int d_rt, dou
     }
     *log_count = slot + 1;
 }
+template <int DT>
+__global__ void tica_grad_kernel(const double* __restrict__ stats, int d_rt, double Bg, double reg, double* __restrict__ gradp,
+                                 double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    tica_grad_body<DT>(stats, d_rt, Bg, reg, gradp, log, log_count, log_cap, log_width);
+}
 
-typedef void (*TicaGradFn)(const double*, int, double, double, float*, double*, int*, int, int);
+typedef void (*TicaGradFn)(const double*, int, double, double, double*, double*, int*, int, int);
 static TicaGradFn tica_grad_fn(int d) {
     switch (d) {
         case 1: return tica_grad_kernel<1>;
@@ -554,51 +496,146 @@ static TicaGradFn tica_grad_fn(int d) {
     }
 }
 
+// The same statistics for D <= 4 outputs with every thread at work: a thread walks whole rows (its pair's
+// 2 D values, 2 D + 2 D^2 float64 accumulators in registers), waves combine by shuffles, the block through
+// LDS.  rows_per_block pairs per block (a multiple of 256; stats_plan): enough blocks to spread a small batch over
+// the chip, few enough partials for the last block's ordered sum.  One launch: the block that finishes last adds the
+// partials up in block order and -- on one GPU, where nothing is all-reduced in between (fused.on) -- goes straight
+// on to the d x d loss head (tica_grad_body), saving the launch of tica_grad_kernel.
+struct FusedHead {
+    int on;            // run tica_grad_body in the last block
+    double Bg, reg;
+    double* gradp;     // null: evaluation only
+    double* log;
+    int* log_count;
+    int log_cap, log_width;
+};
+template <int D>
+__global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __restrict__ F, int64_t ld, int B, int lag_off,
+                                                              int rows_per_block, double* __restrict__ part, unsigned* __restrict__ ticket,
+                                                              double* __restrict__ out, FusedHead fused) {
+    constexpr int W = 2 * D + 2 * D * D;
+    __shared__ double red[4][W];
+    __shared__ unsigned s_last;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double acc[W];
+#pragma unroll
+    for (int o = 0; o < W; ++o) acc[o] = 0.0;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < B ? r0 + rows_per_block : B;
+    for (int64_t r = r0 + t; r < r1; r += 256) {
+        double a[D], b[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            a[i] = (double)F[r * ld + i];
+            b[i] = (double)F[(r + lag_off) * ld + i];
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            acc[i] += a[i];
+            acc[D + i] += b[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                acc[2 * D + i * D + j] += a[i] * a[j];
+                acc[2 * D + D * D + i * D + j] += a[i] * b[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < W; ++o) {
+        double v = acc[o];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) red[wave][o] = v;
+    }
+    __syncthreads();
+    if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    // the block that finishes last adds the partials up in block order (no second launch; same sums whichever
+    // block it is)
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        __threadfence();
+        if (t < W) {
+            double s = 0.0;
+            for (unsigned b = 0; b < gridDim.x; ++b) s += part[(int64_t)b * W + t];
+            out[t] = s;
+            red[0][t] = s;
+        }
+        if (t == 0) *ticket = 0u;
+        if (fused.on) {
+            __syncthreads();
+            if (t == 0) tica_grad_body<D>(&red[0][0], D, fused.Bg, fused.reg, fused.gradp, fused.log, fused.log_count, fused.log_cap, fused.log_width);
+        }
+    }
+}
+typedef void (*tica_stats_fn_t)(const float*, int64_t, int, int, int, double*, unsigned*, double*, FusedHead);
+static tica_stats_fn_t tica_stats_rows_fn(int d) {
+    switch (d) {
+        case 1: return tica_stats_rows_kernel<1>;
+        case 2: return tica_stats_rows_kernel<2>;
+        case 3: return tica_stats_rows_kernel<3>;
+        case 4: return tica_stats_rows_kernel<4>;
+        default: return nullptr;
+    }
+}
+// rows per block of the kernel above: at most 512 blocks, whole multiples of 256 rows
+static int stats_rows_per_block(int64_t batch) { return (int)(cdiv(cdiv(batch, 512), 256) * 256); }
+
 // Gradient of the loss w.r.t. the network outputs.  Sample i (0 <= i < B) has f_t in row i and f_lag in
 // row i + lag_off:  dL/df_t[i] = Gu u_i + Gv v_i + c,  dL/df_lag[i] = Gv u_i  (u = f_t - mu, v = f_lag - mu).
 // Row j of dZ collects whatever lands on it: its own t-gradient (j < B) plus the lag-gradient of sample
 // j - lag_off (j >= lag_off).  With lag_off = B the halves are disjoint; with lag_off = lag (contiguous
 // batch, shared rows) an interior row receives both.  Multiplied by act'(F) of the last layer.
+// Evaluated in float64 from the float64 batch statistics, rounded once: the loss does not change when a constant is
+// added to the outputs, so the exact gradient rows sum to zero over the batch, and every parameter whose gradient is a
+// multiple of that sum (the last bias; the bias of any hidden unit that stays on one side of its ReLU kink over the
+// batch) has an exactly zero gradient.  Adam divides by |g| + 1e-8: a common-mode residue of 1e-5 -- what mu and the
+// matrices rounded to float32 leave -- moves those parameters by a full +-lr per step, where autograd's
+// (g - mean g) leaves 1e-10.  In float64 the rows sum to zero up to their own final rounding, as there.
 __global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ F, int64_t ldf, int B, int d, int lag_off,
-                                                      const float* __restrict__ gradp, int act, float* __restrict__ dZ,
+                                                      const double* __restrict__ gradp, int act, float* __restrict__ dZ,
                                                       int64_t ldz, DropCfg drop, float hscale) {
-    __shared__ float s_g[kMaxTicaDim * (2 * kMaxTicaDim + 2)];
+    __shared__ double s_g[kMaxTicaDim * (2 * kMaxTicaDim + 2)];
     const int np = d + 2 * d * d + d;
     for (int i = threadIdx.x; i < np; i += 256) s_g[i] = gradp[i];
     __syncthreads();
-    const float* mu = s_g;
-    const float* Gu = s_g + d;
-    const float* Gv = Gu + d * d;
-    const float* cv = Gv + d * d;
+    const double* mu = s_g;
+    const double* Gu = s_g + d;
+    const double* Gv = Gu + d * d;
+    const double* cv = Gv + d * d;
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t rows = (int64_t)B + lag_off;
     if (j >= rows) return;
     const bool has_t = j < B;            // row j is the f_t row of sample j
     const bool has_l = j >= lag_off;     // row j is the f_lag row of sample j - lag_off
-    float u[kMaxTicaDim], v[kMaxTicaDim], w[kMaxTicaDim], fj[kMaxTicaDim];
+    double u[kMaxTicaDim], v[kMaxTicaDim], w[kMaxTicaDim];
+    float fj[kMaxTicaDim];
     const float* frow = F + j * ldf;
     for (int i = 0; i < d; ++i) {
         fj[i] = frow[i];
-        u[i] = fj[i] - mu[i];                                               // u_j
-        v[i] = has_t ? F[(j + lag_off) * ldf + i] - mu[i] : 0.f;           // v_j
-        w[i] = has_l ? F[(j - lag_off) * ldf + i] - mu[i] : 0.f;           // u_{j - lag_off}
+        u[i] = (double)fj[i] - mu[i];                                               // u_j
+        v[i] = has_t ? (double)F[(j + lag_off) * ldf + i] - mu[i] : 0.0;           // v_j
+        w[i] = has_l ? (double)F[(j - lag_off) * ldf + i] - mu[i] : 0.0;           // u_{j - lag_off}
     }
     for (int i = 0; i < d; ++i) {
-        float g = 0.f;
+        double g = 0.0;
         if (has_t) {
             g = cv[i];
             for (int q = 0; q < d; ++q) {
-                g = fmaf(Gu[i * d + q], u[q], g);
-                g = fmaf(Gv[i * d + q], v[q], g);
+                g = fma(Gu[i * d + q], u[q], g);
+                g = fma(Gv[i * d + q], v[q], g);
             }
         }
         if (has_l) {
-            float gl = 0.f;
-            for (int q = 0; q < d; ++q) gl = fmaf(Gv[i * d + q], w[q], gl);
+            double gl = 0.0;
+            for (int q = 0; q < d; ++q) gl = fma(Gv[i * d + q], w[q], gl);
             g += gl;
         }
-        if (drop.thr != 0u) g *= f4c(drop.mult(j, i & ~3), i & 3);   // F holds act(z) * keep / (1 - p)
-        dZ[j * ldz + i] = g * act_grad_from_out(act, fj[i] * hscale);
+        float gf = (float)g;
+        if (drop.thr != 0u) gf *= f4c(drop.mult(j, i & ~3), i & 3);   // F holds act(z) * keep / (1 - p)
+        dZ[j * ldz + i] = gf * act_grad_from_out(act, fj[i] * hscale);
     }
 }
 
@@ -616,25 +653,25 @@ __global__ __launch_bounds__(256) void tica_dF_kernel(const float* __restrict__ 
 // fixed order, blocks by reduce_grads_kernel in float64.
 template <int D>
 __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restrict__ F, int64_t ldf, int B, int lag_off,
-                                                            const float* __restrict__ gradp, int act_last,
+                                                            const double* __restrict__ gradp, int act_last,
                                                             const float* __restrict__ H, int64_t ldh, int K, int act_prev,
                                                             const float* __restrict__ W, int64_t rows_per_block,
                                                             float* __restrict__ dZ, int64_t ldz, float* __restrict__ slab,
                                                             float* __restrict__ bpart_last, float* __restrict__ bpart_prev,
                                                             DropCfg drop_prev, float hscale_prev) {
     constexpr int U = 4;                        // rows in flight per thread
-    extern __shared__ float s_mem[];
-    float* s_g = s_mem;                         // mu | Gu | Gv | c
-    float* s_gf = s_mem + (2 * D + 2 * D * D);  // [groups][U][D] loss gradients of the rows in flight
+    extern __shared__ __attribute__((aligned(16))) double s_memd[];
+    double* s_g = s_memd;                       // mu | Gu | Gv | c   (float64: see tica_dF_kernel)
+    float* s_gf = reinterpret_cast<float*>(s_memd + (2 * D + 2 * D * D));  // [groups][U][D] loss gradients of the rows in flight
     const int t = threadIdx.x;
     const int C4 = K / 4, groups = 256 / C4;    // a row group (C4 <= 64 lanes) lies inside one wave
     float* s_red = s_gf + groups * U * D;       // [groups][(D + 1) * K + D]
     for (int i = t; i < 2 * D + 2 * D * D; i += 256) s_g[i] = gradp[i];
     __syncthreads();
-    const float* mu = s_g;
-    const float* Gu = s_g + D;
-    const float* Gv = Gu + D * D;
-    const float* cv = Gv + D * D;
+    const double* mu = s_g;
+    const double* Gu = s_g + D;
+    const double* Gv = Gu + D * D;
+    const double* cv = Gv + D * D;
     const int c4 = t % C4, rl = t / C4;
     const int64_t rows = (int64_t)B + lag_off;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
@@ -665,23 +702,24 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restr
                 if (r < r1) {
                     const bool has_t = r < B, has_l = r >= lag_off;
                     const float* fr = F + r * ldf;
+                    double gd = 0.0;
                     if (has_t) {
-                        gi = cv[i];
+                        gd = cv[i];
                         const float* fv = F + (r + lag_off) * ldf;
 #pragma unroll
                         for (int k = 0; k < D; ++k) {
-                            gi = fmaf(Gu[i * D + k], fr[k] - mu[k], gi);
-                            gi = fmaf(Gv[i * D + k], fv[k] - mu[k], gi);
+                            gd = fma(Gu[i * D + k], (double)fr[k] - mu[k], gd);
+                            gd = fma(Gv[i * D + k], (double)fv[k] - mu[k], gd);
                         }
                     }
                     if (has_l) {
                         const float* fw = F + (r - lag_off) * ldf;
-                        float gl = 0.f;
+                        double gl = 0.0;
 #pragma unroll
-                        for (int k = 0; k < D; ++k) gl = fmaf(Gv[i * D + k], fw[k] - mu[k], gl);
-                        gi += gl;
+                        for (int k = 0; k < D; ++k) gl = fma(Gv[i * D + k], (double)fw[k] - mu[k], gl);
+                        gd += gl;
                     }
-                    gi *= act_grad_from_out(act_last, fr[i]);
+                    gi = (float)gd * act_grad_from_out(act_last, fr[i]);
                 }
                 gmine[q * D + i] = gi;
             }
@@ -734,7 +772,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restr
     }
 }
 
-typedef void (*head_backward_fn_t)(const float*, int64_t, int, int, const float*, int, const float*, int64_t, int, int, const float*, int64_t,
+typedef void (*head_backward_fn_t)(const float*, int64_t, int, int, const double*, int, const float*, int64_t, int, int, const float*, int64_t,
                                    float*, int64_t, float*, float*, float*, DropCfg, float);
 static head_backward_fn_t head_backward_fn(int d) {
     switch (d) {
@@ -884,7 +922,7 @@ static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t*
 // and whose input width tiles a 256-thread block in 16-byte segments
 static size_t head_lds_bytes(int D, int K) {
     const int groups = 256 / (K / 4);
-    return ((size_t)(2 * D + 2 * D * D) + (size_t)groups * 4 * D + (size_t)groups * ((size_t)(D + 1) * K + D)) * sizeof(float);
+    return (size_t)(2 * D + 2 * D * D) * sizeof(double) + ((size_t)groups * 4 * D + (size_t)groups * ((size_t)(D + 1) * K + D)) * sizeof(float);
 }
 static bool head_fusable(const dcv_mlp* m) {
     static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
@@ -989,6 +1027,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->any_drop = false;
     for (int l = 0; l < L; ++l) m->any_drop = m->any_drop || desc->dropout[l] > 0.f;
     m->fwd_train = false;
+    m->head_done = false;
     m->drop_step = 0;
     m->cur_step = 0;
     m->prof_level = m->prof_cap = m->prof_step = 0;
@@ -1305,9 +1344,12 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
     return DCV_OK;
 }
 
+// fuse_head: 0 = statistics only (a data-parallel caller all-reduces them before dcv_mlp_backward); 1 / 2 = one-GPU
+// training / evaluation step: the last block of the statistics launch also runs the loss head (batch = global batch)
 static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
-                        int32_t train, void* stream) {
+                        int32_t train, void* stream, int fuse_head = 0) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_forward: null argument");
+    m->head_done = false;
     m->fwd_train = train != 0;
     if (m->fwd_train) m->cur_step = m->drop_step++;
     DCV_REQUIRE(batch >= 1 && batch <= m->desc.max_batch, "dcv_mlp_forward: batch=%d exceeds max_batch=%d", batch, m->desc.max_batch);
@@ -1321,11 +1363,18 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
         int nb;
         if (tica_stats_fn_t fast = tica_stats_rows_fn(m->d_out)) {
-            nb = (int)cdiv(batch, kFastStatRows);
-            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, (const float*)last.H, last.ldh, (int)batch, lag_offset(m, idx_d, batch), m->spart,
-                               m->ticket, m->stats);
+            const int rpb = stats_rows_per_block(batch);
+            nb = (int)cdiv(batch, rpb);
+            FusedHead fh{0, 0.0, 0.0, nullptr, nullptr, nullptr, 0, 0};
+            if (fuse_head) {
+                DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
+                fh = FusedHead{1, (double)batch, m->desc.tica_reg, fuse_head == 1 ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width};
+            }
+            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, (const float*)last.H, last.ldh, (int)batch, lag_offset(m, idx_d, batch), rpb,
+                               m->spart, m->ticket, m->stats, fh);
             DCV_CHECK_LAUNCH();
             m->last_batch = batch;
+            m->head_done = fuse_head != 0;
             return DCV_OK;
         } else {
             nb = (int)cdiv(batch, kStatBlockRows);
@@ -1346,8 +1395,9 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
     return DCV_OK;
 }
 
+static OptArgs next_opt_args(dcv_mlp* m);
 static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
-                         int64_t global_batch, int32_t train, void* stream) {
+                         int64_t global_batch, int32_t train, void* stream, bool fuse_opt = false) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_backward: null argument");
     if (m->last_batch != batch) {
         set_error("dcv_mlp_backward: batch=%d does not match the preceding forward (%d)", batch, m->last_batch);
@@ -1368,9 +1418,12 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     float* dz_nxt = m->dZ[1];
     bool fused_head = false;
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
-        hipLaunchKernelGGL(tica_grad_fn(m->d_out), dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
-                           train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
-        DCV_CHECK_LAUNCH();
+        if (!m->head_done) {
+            hipLaunchKernelGGL(tica_grad_fn(m->d_out), dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
+                               train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
+            DCV_CHECK_LAUNCH();
+        }
+        m->head_done = false;
         if (!train) return DCV_OK;
         fused_head = head_fusable(m);
         if (!fused_head) {
@@ -1417,7 +1470,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             head_plan(m, R, &kc, &splits);
             prof_mark(m, l, 1, 0, s);
             hipLaunchKernelGGL(head_backward_fn(D), dim3((unsigned)splits), dim3(256), head_lds_bytes(D, K), s, (const float*)p.H, p.ldh,
-                               (int)batch, lag_offset(m, idx_d, batch), (const float*)m->gradp, p.act, (const float*)q.H, q.ldh, K, q.act,
+                               (int)batch, lag_offset(m, idx_d, batch), (const double*)m->gradp, p.act, (const float*)q.H, q.ldh, K, q.act,
                                (const float*)(m->params + p.w_off), kc, dz_nxt, m->ld_dz, p.slab, p.bpart, q.bpart, drop_cfg(m, l - 1),
                                drop_hscale(m, l - 1));
             DCV_CHECK_LAUNCH();
@@ -1476,7 +1529,10 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             dz_nxt = tmp;
         }
     }
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f);
+    OptArgs oa{};
+    if (fuse_opt) oa = next_opt_args(m);
+    hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params, m->adam_m,
+                       m->adam_v, m->opt_aux, oa);
     DCV_CHECK_LAUNCH();
     if (m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
     return DCV_OK;
@@ -1526,9 +1582,8 @@ extern "C" int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h) 
     return DCV_OK;
 }
 
-static int apply_impl(dcv_mlp* m, void* stream) {
-    DCV_REQUIRE(m, "dcv_mlp_apply: null");
-    hipStream_t s = as_stream(stream);
+// arguments of the next optimiser update; advances the step count
+static OptArgs next_opt_args(dcv_mlp* m) {
     m->adam_t += 1;
     const dcv_mlp_desc& d = m->desc;
     const double t = (double)m->adam_t;
@@ -1570,6 +1625,13 @@ static int apply_impl(dcv_mlp* m, void* stream) {
             a.c1 = (float)(m->lr / (1.0 + (t - 1.0) * d.lr_decay));
             break;
     }
+    return a;
+}
+
+static int apply_impl(dcv_mlp* m, void* stream) {
+    DCV_REQUIRE(m, "dcv_mlp_apply: null");
+    hipStream_t s = as_stream(stream);
+    const OptArgs a = next_opt_args(m);
     int64_t blocks = cdiv(m->n_params, 256);
     if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(optimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, s, m->params, (const float*)m->grads, m->adam_m, m->adam_v,
@@ -1603,11 +1665,9 @@ extern "C" int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, con
                                   void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_train_step: null");
     return run_graphed(m, 0, as_stream(stream), [&] {
-        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 1, stream);
+        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 1, stream, 1);
         if (rc) return rc;
-        rc = backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream);
-        if (rc) return rc;
-        return apply_impl(m, stream);
+        return backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream, true);   // reduction + optimiser update in one launch
     });
 }
 
@@ -1615,7 +1675,7 @@ extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, cons
                                  void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_eval_step: null");
     return run_graphed(m, 3, as_stream(stream), [&] {
-        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 0, stream);
+        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 0, stream, 2);
         if (rc) return rc;
         return backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 0, stream);
     });

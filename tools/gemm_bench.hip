@@ -78,7 +78,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dZ, (size_t)R * H1 * 4));
     CK(hipMalloc(&W2, (size_t)H2 * H1 * 4));
     CK(hipMalloc(&H2b, (size_t)R * H2 * 4));
-    const int64_t slab_cap = (R + 511) / 512 + 1;   // slabs of H1 x F floats: one per smallest k-chunk; launch_gemm refuses more splits than this
+    const int64_t slab_cap = (R + 255) / 256 + 1;   // slabs of H1 x F floats: one per smallest k-chunk (256 rows); launch_gemm refuses more splits than this
     CK(hipMalloc(&slab, (size_t)slab_cap * H1 * F * 4));
     CK(hipMalloc(&bpart, (size_t)(R / 32 + 8) * H1 * 4));
     std::vector<float> h((size_t)R * F);
@@ -98,11 +98,11 @@ int main(int argc, char** argv) {
         EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};
         double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, it);
         printf("L0 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);
-        dump_stamps("L0 fwd", (int)(R / 128 * 2));
+        dump_stamps("L0 fwd", (int)(R / 128 * 2 > 0 ? R / 128 * 2 : 1));
     }
     {   // L0 wgrad: dZ[R,256]^T x X[R,512], split
         Operand A = make_operand(dZ, H1, H1), B = make_operand(X, F, F);
-        for (int64_t kc : {1024, 2048, 4096}) {
+        for (int64_t kc : (R < 32768 ? std::vector<int64_t>{256, 512, 1024} : std::vector<int64_t>{1024, 2048, 4096})) {
             EpiSlab epi{slab, H1, F, 1, 0, true, slab_cap};
             double ms = time_ms([&] { launch_gemm<kTN, EpiSlab>(A, B, H1, F, R, kc, epi, s); }, it);
             printf("L0 wgrad TN kc=%5lld %8.1f us  %6.1f TF\n", (long long)kc, ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);
@@ -124,7 +124,7 @@ int main(int argc, char** argv) {
     }
     {   // L1 wgrad: dZ2[R,128]^T x H1[R,256]
         Operand A = make_operand(H2b, H2, H2), B = make_operand(Hb, H1, H1);
-        for (int64_t kc : {512, 1024, 2048}) {
+        for (int64_t kc : (R < 32768 ? std::vector<int64_t>{256, 512, 1024} : std::vector<int64_t>{512, 1024, 2048})) {
             EpiSlab epi{slab, H2, H1, 1, 0, true, slab_cap};
             double ms = time_ms([&] { launch_gemm<kTN, EpiSlab>(A, B, H2, H1, R, kc, epi, s); }, it);
             printf("L1 wgrad TN kc=%5lld %8.1f us  %6.1f TF\n", (long long)kc, ms * 1e3, 2.0 * R * H2 * H1 / ms / 1e9);

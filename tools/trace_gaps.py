@@ -1,5 +1,5 @@
 """Per-step timeline from a rocprofv3 --kernel-trace CSV dir: busy time, idle gaps between consecutive
-dcv kernels, per-kernel share; steady-state window = the last `nsteps` adam_kernel launches."""
+dcv kernels, per-kernel share; steady-state window = the last `nsteps` reduce_grads_kernel launches (one per optimiser step)."""
 import csv
 import glob
 import os
@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-adam = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+adam = [i for i, r in enumerate(rows) if "reduce_grads_kernel" in r[2]]   # one per optimiser step (the update is fused into it)
 lo, hi = adam[-nsteps - 1], adam[-1]
 win = rows[lo + 1: hi + 1]
 span = win[-1][1] - win[0][0]

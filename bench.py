@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: Deep-TICA training frames/sec on a synthetic 10M x 512 feature matrix
-(BASELINE.json metric), frame-sharded over N GPUs.
+(BASELINE.json metric; SURVEY.md section 8d / BASELINE.md config C4: MLP 512-256-128-4, lag 10,
+global batch 8192 pairs), frame-sharded over N GPUs.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -9,7 +10,9 @@ A step is one optimiser step over one global batch of time-lagged pairs.  The ma
 generated on the device, standardised by the HIP statistics / normalise kernels and stays
 resident in HBM; the timed region holds exactly K training steps (plus the validation pass at
 every epoch boundary they cross, as the reference's fit loop does) between barriers.  Rank 0
-prints one JSON line."""
+prints one JSON line.  `value` is the contract configuration (global batch 8192); the same fit at
+a large global batch (524 208 pairs: MFMA-bound instead of latency-bound) is reported beside it
+under `large_batch`, with its own roofline."""
 import argparse
 import json
 import os
@@ -30,27 +33,26 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # same guide, BF16 MFMA (dense); the split arith
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=120)
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--steps", type=int, default=2000)
+    p.add_argument("--warmup", type=int, default=100)
     p.add_argument("--frames", type=int, default=10_000_000)
     p.add_argument("--features", type=int, default=512)
     p.add_argument("--hidden", type=str, default="256,128")
     p.add_argument("--dim", type=int, default=4)
     p.add_argument("--lag", type=int, default=10)
-    p.add_argument("--batch", type=int, default=524208,
-                   help="global batch (pairs per optimiser step); default 8 x (65536 - lag): every rank's step covers whole "
-                        "128-row tiles at 1/2/4/8 GPUs when the rows of x_t and x_lag are shared")
+    p.add_argument("--batch", type=int, default=8192, help="global batch (pairs per optimiser step) of the headline: SURVEY 8d / BASELINE.md C4")
     p.add_argument("--lr", type=float, default=1e-3)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
-    p.add_argument("--profile-level", type=int, default=1)
-    p.add_argument("--alt-batch", type=int, default=8192,
-                   help="also report (field 'secondary') the throughput at this global batch -- the size SURVEY.md 8d floated; 0 disables")
-    p.add_argument("--alt-steps", type=int, default=300)
+    p.add_argument("--profile-every", type=int, default=8, help="HIP events around the layer-0 products on every n-th timed step")
+    p.add_argument("--large-batch", type=int, default=524208,
+                   help="second measurement ('large_batch'): 8 x (65536 - lag) pairs -- every rank's step covers whole 128-row "
+                        "tiles at 1/2/4/8 GPUs when the rows of x_t and x_lag are shared; 0 disables")
+    p.add_argument("--large-steps", type=int, default=60)
     p.add_argument("--gemm-mode", choices=["split", "native"], default="split",
                    help="arithmetic of the MLP products: 'split' = FP32-accurate split products on the BF16 matrix pipe "
                         "(library default), 'native' = FP32-input MFMA; the other mode is timed too (field 'other_gemm_mode')")
-    p.add_argument("--other-mode-steps", type=int, default=40)
+    p.add_argument("--other-mode-steps", type=int, default=200)
     return p.parse_args()
 
 
@@ -89,10 +91,126 @@ def cpu_baseline(Xn_host, dims, acts, lag, batch, lr, seconds, linears):
     while True:
         step(done + 1)
         done += 1
-        if time.perf_counter() - t0 >= seconds or done >= 200:
+        if time.perf_counter() - t0 >= seconds or done >= 2000:
             break
     dt = time.perf_counter() - t0
     return done * batch / dt, done, dt
+
+
+class Fit:
+    """The Deep-TICA fit loop of one rank at a given global batch: K optimiser steps over consecutive batches of the
+    resident matrix (lengths [0.8, 0.2], sequential split, no shuffling), the validation pass at every epoch boundary."""
+
+    def __init__(self, hip, dist, Xn, dims, acts, lag, global_batch, world, lr, linears, n_local):
+        self.hip, self.dist, self.Xn, self.dims, self.lag = hip, dist, Xn, dims, lag
+        self.gb = global_batch
+        self.lb = global_batch // world
+        P_local = n_local - lag
+        self.n_train = int(P_local * 0.8) // self.lb * self.lb
+        self.steps_per_epoch = self.n_train // self.lb
+        self.val_steps = (P_local - self.n_train) // self.lb
+        assert self.steps_per_epoch >= 1, "shard too small for the batch"
+        self.eng = hip.Mlp("deep_tica", dims, acts, max_batch=self.lb, lag=lag, tica_reg=1e-6, lr=lr)
+        self.eng.set_linears(linears)
+        self.sv, self.gv = self.eng.stats_view(), self.eng.grads_view()
+
+    def train_step(self, i):
+        eng, r0 = self.eng, (i % self.steps_per_epoch) * self.lb
+        if self.dist is None:
+            eng.train_step(self.Xn, row0=r0, batch=self.lb)
+        else:
+            eng.forward(self.Xn, row0=r0, batch=self.lb)
+            self.dist.all_reduce(self.sv, op=self.dist.ReduceOp.SUM)
+            eng.backward(self.Xn, row0=r0, batch=self.lb, global_batch=self.gb, train=True)
+            self.dist.all_reduce(self.gv, op=self.dist.ReduceOp.SUM)
+            eng.apply()
+
+    def validation_pass(self):
+        eng = self.eng
+        for j in range(self.val_steps):
+            r0 = self.n_train + j * self.lb
+            if self.dist is None:
+                eng.eval_step(self.Xn, row0=r0, batch=self.lb)
+            else:
+                eng.forward(self.Xn, row0=r0, batch=self.lb, train=False)
+                self.dist.all_reduce(self.sv, op=self.dist.ReduceOp.SUM)
+                eng.backward(self.Xn, row0=r0, batch=self.lb, global_batch=self.gb, train=False)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup, profile_every, with_validation=True):
+        """Times exactly `steps` optimiser steps between barriers; returns (seconds [max over ranks], per-kernel
+        profile {(layer, kind): (total ms, launches)}, log records)."""
+        eng = self.eng
+        n_val = (steps // self.steps_per_epoch + 2) * (self.val_steps + 1)
+        eng.reset_log((steps + warmup) * 2 + n_val + 16)
+        for i in range(warmup):
+            self.train_step(i)
+        self.barrier()
+        sampled = max(1, steps // max(1, profile_every)) + 1
+        if profile_every > 0:
+            eng.profile_begin(sampled, 1)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if profile_every > 1:
+                eng.profile_pause(i % profile_every != 0)
+            self.train_step(i)
+            if with_validation and (i + 1) % self.steps_per_epoch == 0:
+                self.validation_pass()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        prof = eng.profile_end() if profile_every > 0 else {}
+        log = eng.read_log()
+        if self.dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.Xn.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, prof, log
+
+    def roofline(self, prof, gemm_mode, traffic_table):
+        """Roofline object of the slower layer-0 product (the dominant kernel of the step): algorithmic flop of one
+        launch / its mean duration between HIP events on the launch stream, against the ceiling of the arithmetic."""
+        if not prof:
+            return None
+        R = self.lb + self.lag   # contiguous batches: the network runs once on the batch + lag rows both halves share
+        per = {f"layer{l}.{k}": (2.0 * R * self.dims[l] * self.dims[l + 1], ms / cnt) for (l, k), (ms, cnt) in prof.items()}
+        name, (fl, ms) = max(per.items(), key=lambda kv: kv[1][1])
+        achieved = fl / (ms * 1e-3) / 1e12
+        if gemm_mode == "split":
+            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
+            kname = f"{name} (gemm_kernel, 6 x v_mfma_f32_32x32x16_bf16 per FP32-accurate 32x32x16 block)"
+            note = ("algorithmic fp32 flop / time against the BF16 dense MFMA peak (2500 TFLOP/s) / 6 products per block; "
+                    f"the same rate is {achieved / PEAK_F32_MFMA_TFLOPS:.2f} x the FP32-input MFMA peak of {PEAK_F32_MFMA_TFLOPS} TFLOP/s")
+        else:
+            peak = PEAK_F32_MFMA_TFLOPS
+            kname = f"{name} (gemm_kernel, FP32 MFMA 32x32x2)"
+            note = "algorithmic fp32 flop / time against the FP32-input MFMA dense peak"
+        traffic = None
+        for entry in traffic_table:
+            if entry.get("rows_per_launch") == R and entry.get("gemm_mode", "split") == gemm_mode:
+                traffic = entry.get("kernels", {}).get(name, {}).get("hbm_bytes_per_launch")
+        return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+                "kernel": kname, "rows_per_launch": R, "flop_per_launch": fl, "avg_ms": ms,
+                "all_kernels_ms": {k: v[1] for k, v in sorted(per.items())}, "note": note}
+
+    def close(self):
+        self.eng.close()
+
+
+def load_traffic_tables():
+    out = []
+    pdir = os.path.join(ROOT, "profiles")
+    for fn in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if fn.startswith("traffic_") and fn.endswith(".json"):
+            try:
+                tj = json.load(open(os.path.join(pdir, fn)))
+            except Exception:
+                continue
+            out.extend(tj if isinstance(tj, list) else [tj])
+    return out
 
 
 def main():
@@ -124,13 +242,7 @@ def main():
     dims = [F] + [int(x) for x in a.hidden.split(",") if x] + [d]
     acts = ["leaky_relu"] * (len(dims) - 2) + [None]
     assert a.batch % world == 0
-    lb = a.batch // world                      # pairs per rank per step
     n_local = a.frames // world                # frames of this rank's shard (an independent trajectory)
-    P_local = n_local - lag
-    n_train = int(P_local * 0.8) // lb * lb    # lengths [0.8, 0.2], random_split False, shuffle False
-    steps_per_epoch = n_train // lb
-    val_steps = (P_local - n_train) // lb
-    assert steps_per_epoch >= 1, "shard too small for the batch"
 
     # ---- data: generate on the device, standardise with the HIP kernels, keep resident
     X = synth_features(n_local, F, k_slow=4, shard=rank, device=dev)
@@ -153,114 +265,43 @@ def main():
 
     hip.set_gemm_mode(a.gemm_mode)
     linears = init_linears(dims, 43)
-    eng = hip.Mlp("deep_tica", dims, acts, max_batch=lb, lag=lag, tica_reg=1e-6, lr=a.lr)
-    eng.set_linears(linears)
-    stats_v = eng.stats_view()
-    grads_v = eng.grads_view()
-    n_records = (a.steps + a.warmup) * 2 + (a.steps // steps_per_epoch + 2) * (val_steps + 1) + 16
-    eng.reset_log(n_records)
+    traffic_tables = load_traffic_tables()
 
-    def train_step(i):
-        r0 = (i % steps_per_epoch) * lb
-        if dist is None:
-            eng.train_step(Xn, row0=r0, batch=lb)
-        else:
-            eng.forward(Xn, row0=r0, batch=lb)
-            dist.all_reduce(stats_v, op=dist.ReduceOp.SUM)
-            eng.backward(Xn, row0=r0, batch=lb, global_batch=a.batch, train=True)
-            dist.all_reduce(grads_v, op=dist.ReduceOp.SUM)
-            eng.apply()
+    # ---- headline: the contract batch
+    fit = Fit(hip, dist, Xn, dims, acts, lag, a.batch, world, a.lr, linears, n_local)
+    elapsed, prof, log = fit.run(a.steps, a.warmup, a.profile_every)
+    head_roof = fit.roofline(prof, a.gemm_mode, traffic_tables) if rank == 0 else None
 
-    def validation_pass():
-        for j in range(val_steps):
-            r0 = n_train + j * lb
-            if dist is None:
-                eng.eval_step(Xn, row0=r0, batch=lb)
-            else:
-                eng.forward(Xn, row0=r0, batch=lb, train=False)
-                dist.all_reduce(stats_v, op=dist.ReduceOp.SUM)
-                eng.backward(Xn, row0=r0, batch=lb, global_batch=a.batch, train=False)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(a.warmup):
-        train_step(i)
-    barrier()
-    eng.profile_begin(a.steps, a.profile_level)
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        train_step(i)
-        if (i + 1) % steps_per_epoch == 0:
-            validation_pass()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = eng.profile_end()
-    log = eng.read_log()
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- the same training steps in the other arithmetic mode (the mode is a launch-time switch of the library)
+    # the same training steps in the other arithmetic mode (a launch-time switch of the library)
     other = "native" if a.gemm_mode == "split" else "split"
     other_res = None
     if a.other_mode_steps > 0:
         hip.set_gemm_mode(other)
-        for i in range(5):
-            train_step(i)
-        barrier()
-        eng.profile_begin(a.other_mode_steps, 1)
-        t0o = time.perf_counter()
-        for i in range(a.other_mode_steps):
-            train_step(i)
-        barrier()
-        elo = time.perf_counter() - t0o
-        prof_o = eng.profile_end()
+        elo, prof_o, _ = fit.run(a.other_mode_steps, 20, a.profile_every, with_validation=False)
         hip.set_gemm_mode(a.gemm_mode)
-        if dist is not None:
-            t = torch.tensor([elo], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elo = float(t.item())
-        other_res = {"gemm_mode": other, "value": a.other_mode_steps * a.batch / elo, "unit": "frames/s",
-                     "ms_per_step": elo / a.other_mode_steps * 1e3, "steps": a.other_mode_steps,
-                     "note": "training steps only (no validation pass), same engine state, arithmetic switched at launch time"}
-        if prof_o:   # the same roofline line for the other arithmetic: slower layer-0 product against that arithmetic's ceiling
-            (ol_, ok_), (oms, ocnt) = max(prof_o.items(), key=lambda kv: kv[1][0] / kv[1][1])
-            ofl = 2.0 * (lb + lag) * dims[ol_] * dims[ol_ + 1]
-            oach = ofl / (oms / ocnt * 1e-3) / 1e12
-            opeak = PEAK_F32_MFMA_TFLOPS if other == "native" else PEAK_BF16_MFMA_TFLOPS / 6.0
-            other_res["roofline"] = {"bound": "mfma", "kernel": f"layer{ol_}.{ok_}", "achieved": oach, "peak": opeak, "unit": "TFLOP/s",
-                                     "frac": oach / opeak, "avg_ms": oms / ocnt}
+        if rank == 0:
+            other_res = {"gemm_mode": other, "value": a.other_mode_steps * a.batch / elo, "unit": "frames/s",
+                         "ms_per_step": elo / a.other_mode_steps * 1e3, "steps": a.other_mode_steps,
+                         "note": "training steps only (no validation pass), same engine, arithmetic switched at launch time"}
+            r = fit.roofline(prof_o, other, traffic_tables)
+            if r:
+                other_res["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms")}
+    steps_per_epoch, val_steps = fit.steps_per_epoch, fit.val_steps
+    fit.close()
+
+    # ---- the same fit at a large global batch (MFMA-bound instead of launch / latency-bound)
+    large = None
+    if a.large_batch > 0 and a.large_batch % world == 0 and a.large_batch != a.batch and (n_local - lag) * 0.8 >= a.large_batch // world:
+        fl_ = Fit(hip, dist, Xn, dims, acts, lag, a.large_batch, world, a.lr, linears, n_local)
+        el, prof_l, _ = fl_.run(a.large_steps, 5, 1)
+        if rank == 0:
+            large = {"global_batch": a.large_batch, "value": a.large_steps * a.large_batch / el, "unit": "frames/s",
+                     "ms_per_step": el / a.large_steps * 1e3, "steps": a.large_steps, "steps_per_epoch": fl_.steps_per_epoch,
+                     "roofline": fl_.roofline(prof_l, a.gemm_mode, traffic_tables),
+                     "note": "same matrix, model, split and arithmetic; validation pass at each epoch boundary inside the timed region"}
+        fl_.close()
 
     if rank == 0:
-        R = lb + lag   # contiguous batches: the network runs once on the batch + lag rows both halves share
-        flops = {}
-        for (layer, kind), (ms, cnt) in prof.items():
-            fl = 2.0 * R * dims[layer] * dims[layer + 1]
-            flops[(layer, kind)] = (fl, ms / cnt)
-        (dl, dk), (dfl, dms) = max(flops.items(), key=lambda kv: kv[1][1])
-        achieved = dfl / (dms * 1e-3) / 1e12
-        # HBM bytes per launch of that kernel from the committed rocprofv3 PMC passes (same launch shape)
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
-        if os.path.exists(tpath) and F == 512 and dims[1] == 256:
-            tj = json.load(open(tpath))
-            if tj.get("rows_per_launch") == R:
-                traffic = tj["kernels"].get(f"layer{dl}.{dk}", {}).get("hbm_bytes_per_launch")
-        if a.gemm_mode == "split":
-            # every fp32 flop is 6 bf16 MFMA flops: the ceiling of this arithmetic is the BF16 pipe's dense peak / 6
-            peak = PEAK_BF16_MFMA_TFLOPS / 6.0
-            kname = f"layer{dl}.{dk} (gemm_kernel, 6 x v_mfma_f32_32x32x16_bf16 per FP32-accurate 32x32x16 block)"
-            peak_note = ("algorithmic fp32 flop / time against the BF16 dense MFMA peak (2500 TFLOP/s) / 6 products per block; "
-                         f"the same rate is {achieved / PEAK_F32_MFMA_TFLOPS:.2f} x the FP32-input MFMA peak of {PEAK_F32_MFMA_TFLOPS} TFLOP/s "
-                         "(which bounds --gemm-mode native, timed in 'other_gemm_mode')")
-        else:
-            peak = PEAK_F32_MFMA_TFLOPS
-            kname = f"layer{dl}.{dk} (gemm_kernel, FP32 MFMA 32x32x2)"
-            peak_note = "algorithmic fp32 flop / time against the FP32-input MFMA dense peak"
         sw = sum(dims[i] * dims[i + 1] + dims[i + 1] for i in range(len(dims) - 1))
         losses = log[:, 0]
         out = {
@@ -281,77 +322,28 @@ def main():
                            "always use the FP32-input MFMA"),
             "data": "synthetic",
             "config": {
-                "workload": f"Deep-TICA fit, {a.frames}x{F} f32 synthetic AR(1) features (SURVEY 8d, C4), MLP {'-'.join(map(str, dims))}, "
+                "workload": f"Deep-TICA fit (BASELINE.md C4), {a.frames}x{F} f32 synthetic AR(1) features (SURVEY 8d), MLP {'-'.join(map(str, dims))}, "
                             f"lag {lag}, global batch {a.batch} pairs, Adam lr {a.lr}, lengths [0.8,0.2], sequential split, "
                             f"validation pass at each epoch end inside the timed region; contiguous batches evaluate the "
                             f"batch + lag rows shared by x_t and x_lag once",
                 "frames": a.frames, "features": F, "global_batch": a.batch, "parallelism": f"frame-shard dp{world}",
-                "steps_per_epoch": steps_per_epoch, "val_steps_per_epoch": val_steps, "params": sw,
+                "steps_per_epoch": steps_per_epoch, "val_steps_per_epoch": val_steps, "params": sw, "gemm_mode": a.gemm_mode,
             },
             "loss_first": float(losses[0]) if len(losses) else None,
             "loss_last_train": float(losses[-1]) if len(losses) else None,
-            "roofline": {
-                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic,
-                "kernel": kname, "flop_per_launch": dfl, "avg_ms": dms,
-                "all_kernels_ms": {f"layer{l}.{k}": v[1] for (l, k), v in sorted(flops.items())},
-                "note": peak_note,
-            },
+            "roofline": head_roof,
         }
-        out["config"]["gemm_mode"] = a.gemm_mode
         if other_res is not None:
             out["other_gemm_mode"] = other_res
-    eng.close()
-    # ---- secondary: the same fit at the small global batch of SURVEY 8d (launch-latency bound; every rank runs it)
-    alt = None
-    if a.alt_batch > 0 and a.alt_batch % world == 0 and a.alt_batch != a.batch:
-        alb = a.alt_batch // world
-        a_train = int(P_local * 0.8) // alb * alb
-        a_spe = a_train // alb
-        if a_spe >= 1:
-            eng2 = hip.Mlp("deep_tica", dims, acts, max_batch=alb, lag=lag, tica_reg=1e-6, lr=a.lr)
-            eng2.set_linears(linears)
-            sv2, gv2 = eng2.stats_view(), eng2.grads_view()
-            eng2.reset_log(a.alt_steps + 64)
-
-            def alt_step(i):
-                r0 = (i % a_spe) * alb
-                if dist is None:
-                    eng2.train_step(Xn, row0=r0, batch=alb)
-                else:
-                    eng2.forward(Xn, row0=r0, batch=alb)
-                    dist.all_reduce(sv2, op=dist.ReduceOp.SUM)
-                    eng2.backward(Xn, row0=r0, batch=alb, global_batch=a.alt_batch, train=True)
-                    dist.all_reduce(gv2, op=dist.ReduceOp.SUM)
-                    eng2.apply()
-
-            for i in range(50):
-                alt_step(i)
-            barrier()
-            t0 = time.perf_counter()
-            for i in range(a.alt_steps):
-                alt_step(i)
-            barrier()
-            el = time.perf_counter() - t0
-            if dist is not None:
-                t = torch.tensor([el], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                el = float(t.item())
-            alt = {"global_batch": a.alt_batch, "value": a.alt_steps * a.alt_batch / el, "unit": "frames/s",
-                   "ms_per_step": el / a.alt_steps * 1e3, "steps": a.alt_steps,
-                   "note": "training steps only, same matrix / model / split; launch-latency bound at this size"}
-            eng2.close()
-    if rank == 0:
-        if alt is not None:
-            out["secondary"] = alt
+        if large is not None:
+            out["large_batch"] = large
         if not a.no_cpu_baseline and world == 1:
-            cpu_batch = min(a.batch, 65536)   # bounded sample: frames/s of the CPU GEMMs does not depend on the batch size
-            sample_rows = min(n_local, 4 * cpu_batch + lag)
+            sample_rows = min(n_local, 40 * a.batch + lag)
             Xh = Xn[:sample_rows].cpu().numpy()
-            v, done, dt = cpu_baseline(Xh, dims, acts, lag, min(cpu_batch, sample_rows - lag), a.lr, a.cpu_seconds, linears)
+            v, done, dt = cpu_baseline(Xh, dims, acts, lag, min(a.batch, sample_rows - lag), a.lr, a.cpu_seconds, linears)
             out["cpu_baseline"] = {
                 "value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, batches of {cpu_batch} pairs) on the first "
+                "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, batches of {a.batch} pairs) on the first "
                           f"{sample_rows} frames, {dt:.1f} s",
             }
         print(json.dumps(out))

@@ -702,6 +702,18 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
             for (int j = 0; j < FN; ++j) split3(f.b[b][j], p.b1[b][j], p.b2[b][j], p.b3[b][j]);
     };
+    // Makes the planes opaque at this point of the program: their split must have been computed by here (the compiler
+    // otherwise sinks it to the first use, on the far side of a stage barrier).
+    auto pin_planes = [&](Planes& p) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            asm volatile("" : "+v"(p.a1[i]), "+v"(p.a2[i]), "+v"(p.a3[i]));
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(p.b1[b][j]), "+v"(p.b2[b][j]), "+v"(p.b3[b][j]));
+    };
     // six products per accumulator tile, small cross terms first; `between(k)` runs after the k-th product type
     // (k = 0..5) -- the stage boundary hangs its scalar DMA issue there, under MFMAs already in flight
     auto mfma_planes = [&](const Planes& p, auto&& between) {
@@ -850,12 +862,57 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             // same ring, 16-deep steps: the last step of a stage is multiplied after the boundary work
             constexpr int S = KB / 16;
             Frags8 f0, f1;
+#ifdef DCV_PIPE_SPLIT
+            Planes pl0, pl1;
+#endif
             read_frags8(f0, lds, lds + A_SZ, 0);
+#ifdef DCV_PIPE_SPLIT
+            if constexpr (S == 2) split_frags(f0, pl0);
+#endif
             int cur_buf = 0;
             for (int64_t st = 0; st < nst; ++st) {
                 const float* la = lds + cur_buf * STAGE;
                 const float* lb = la + A_SZ;
                 const int nxt_buf = cur_buf + 1 == NBUF ? 0 : cur_buf + 1;
+#ifdef DCV_PIPE_SPLIT
+                if constexpr (S == 2) {
+                    // Software pipeline over the 16-deep steps: the six bf16 products of step s run from planes that were
+                    // split while step s - 1 was being multiplied, and the operands of step s + 1 are split under them --
+                    // one wave keeps the matrix pipe and the vector ALU busy together instead of in turns (with a single
+                    // workgroup per CU, the small-batch case, nobody else fills the gaps).  sched_group_barrier asks for
+                    // one MFMA followed by VPM vector-ALU instructions, over and over.
+                    constexpr int NMF = 6 * NB * FM * FN;                      // MFMAs of a step
+                    constexpr int NVA = 44 * (FM + NB * FN);                   // vector-ALU instructions of its split
+                    constexpr int VPM = (NVA + NMF - 1) / NMF;
+                    read_frags8(f1, la, lb, 1);
+                    mfma_planes(pl0, [](int) {});
+                    split_frags(f1, pl1);
+                    pin_planes(pl1);
+#pragma unroll
+                    for (int q = 0; q < NMF; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    vm_wait_younger<NBUF - 2, GL>(nst - 2 - st);
+                    __syncthreads();
+                    read_frags8(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
+                    const bool more = st + NBUF < nst;
+                    const int64_t k_next = k_begin + (st + NBUF) * KB;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) glds_stage(k_next, cur_buf, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mfma_planes(pl1, [](int) {});
+                    split_frags(f0, pl0);
+                    pin_planes(pl0);
+#pragma unroll
+                    for (int q = 0; q < NMF; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else
+#endif
                 if constexpr (S == 2) {
                     read_frags8(f1, la, lb, 1);
                     mfma16(f0);

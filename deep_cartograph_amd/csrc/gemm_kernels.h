@@ -138,25 +138,25 @@ struct EpiBiasAct {  // H = dropout(act(acc + bias[col]))
 // adds the partner's copy of that half), odd counts fall back to an all-reduce step.  Afterwards x[i],
 // i < the returned count, holds the full sum of original entry base + i; lanes that differ only in the
 // bits of `dup` hold copies.
-template <int CUR, int OFF, int MAXN>
-__device__ __forceinline__ int butterfly_sum(float (&x)[MAXN], int lane, int& base, int& dup) {
+template <int CUR, int OFF, int MAXN, class T = float>
+__device__ __forceinline__ int butterfly_sum(T (&x)[MAXN], int lane, int& base, int& dup) {
     if constexpr (OFF >= 1) {
         if constexpr (CUR % 2 == 0) {
             constexpr int H = CUR / 2;
             const bool up = (lane & OFF) != 0;
 #pragma unroll
             for (int i = 0; i < H; ++i) {
-                const float send = up ? x[i] : x[i + H];
-                const float keep = up ? x[i + H] : x[i];
+                const T send = up ? x[i] : x[i + H];
+                const T keep = up ? x[i + H] : x[i];
                 x[i] = keep + __shfl_xor(send, OFF, 64);
             }
             base += up ? H : 0;
-            return butterfly_sum<H, OFF / 2, MAXN>(x, lane, base, dup);
+            return butterfly_sum<H, OFF / 2, MAXN, T>(x, lane, base, dup);
         } else {
 #pragma unroll
             for (int i = 0; i < CUR; ++i) x[i] += __shfl_xor(x[i], OFF, 64);
             dup |= OFF;
-            return butterfly_sum<CUR, OFF / 2, MAXN>(x, lane, base, dup);
+            return butterfly_sum<CUR, OFF / 2, MAXN, T>(x, lane, base, dup);
         }
     } else {
         return CUR;

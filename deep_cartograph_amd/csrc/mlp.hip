@@ -251,6 +251,43 @@ __global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs
     }
 }
 
+// The same reduction for small split counts (small batches: the 16-wave form above spends a 1024-thread block on 64
+// outputs and a handful of partials): a block covers 64 consecutive elements, its four waves take the partials
+// q = wave, wave + 4, ... (independent loads, eight in flight per thread: a serial walk over the 257 partials of the
+// fused last-layer pass cost 64 us of load latency) and are combined in wave order; float64, fixed order, optional
+// fused optimiser update.
+__global__ __launch_bounds__(256) void reduce_grads_small_kernel(ReduceArgs a, float* __restrict__ grads, float scale, int fuse,
+                                                                 float* __restrict__ params, float* __restrict__ s1,
+                                                                 float* __restrict__ s2, float* __restrict__ s3, OptArgs oa) {
+    __shared__ double s_red[4][64];
+    const ReduceDesc& d = a.l[blockIdx.y];
+    const int64_t total = d.w_count + d.out;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
+        double s = 0.0;
+        if (i < d.w_count) {
+            const float* p = d.slab + i;
+#pragma unroll 8
+            for (int q = wave; q < d.splits; q += 4) s += (double)p[(int64_t)q * d.w_count];
+        } else if (i < total) {
+            const float* p = d.bpart + (i - d.w_count);
+#pragma unroll 8
+            for (int q = wave; q < d.bblocks; q += 4) s += (double)p[(int64_t)q * d.out];
+        }
+        s_red[wave][lane] = s;
+        __syncthreads();
+        if (wave == 0 && i < total) {
+            const double tot = ((s_red[0][lane] + s_red[1][lane]) + s_red[2][lane]) + s_red[3][lane];
+            const float g = (float)(tot * (double)scale);
+            const int64_t pidx = i < d.w_count ? d.w_off + i : d.b_off + (i - d.w_count);
+            grads[pidx] = g;
+            if (fuse) opt_update(pidx, g, params, s1, s2, s3, oa);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------ Deep-TICA batch statistics
 // F: f_t of sample r in row r, f_lag in row r + lag_off, d columns (lag_off = B when the two halves
 // of the batch are separate rows, = lag when a contiguous batch shares its rows: see dcv_mlp_forward).
@@ -335,8 +372,11 @@ __device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats,
                                                double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
     constexpr int DM = DT > 0 ? DT : kMaxTicaDim;
     const int d = DT > 0 ? DT : d_rt;
-    double mu[DM], ml[DM];
+    // one thread, a dependent chain: float64 divisions (a ~30-instruction sequence each) are replaced by multiplications
+    // with 1 / B and the reciprocals of the Cholesky diagonal -- 1 + d divisions instead of ~8 d^2
+    double mu[DM], ml[DM], invL[DM];
     double C0[DM * DM], Ct[DM * DM], A[DM * DM], K[DM * DM], T[DM * DM], Lc[DM * DM];
+    const double invB = 1.0 / Bg;
     const double* sft = stats;
     const double* sfl = stats + d;
     const double* Stt = stats + 2 * d;
@@ -344,17 +384,17 @@ __device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats,
 #pragma unroll
     for (int i = 0; i < DM; ++i)
         if (i < d) {
-            mu[i] = sft[i] / Bg;
-            ml[i] = sfl[i] / Bg;
+            mu[i] = sft[i] * invB;
+            ml[i] = sfl[i] * invB;
         }
 #pragma unroll
     for (int i = 0; i < DM; ++i)
 #pragma unroll
         for (int j = 0; j < DM; ++j)
             if (i < d && j < d) {
-                C0[i * DM + j] = 0.5 * (Stt[i * d + j] + Stt[j * d + i]) / Bg - mu[i] * mu[j];
-                const double cij = Stl[i * d + j] / Bg - mu[i] * ml[j];
-                const double cji = Stl[j * d + i] / Bg - mu[j] * ml[i];
+                C0[i * DM + j] = 0.5 * (Stt[i * d + j] + Stt[j * d + i]) * invB - mu[i] * mu[j];
+                const double cij = Stl[i * d + j] * invB - mu[i] * ml[j];
+                const double cji = Stl[j * d + i] * invB - mu[j] * ml[i];
                 Ct[i * DM + j] = 0.5 * (cij + cji);
             }
     // Cholesky of C0 + reg I
@@ -371,8 +411,9 @@ __device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats,
                 if (i == j) {
                     if (!(s > 0.0)) ok = false;
                     Lc[i * DM + i] = sqrt(s);
+                    invL[i] = 1.0 / Lc[i * DM + i];
                 } else {
-                    Lc[i * DM + j] = s / Lc[j * DM + j];
+                    Lc[i * DM + j] = s * invL[j];
                 }
             }
     // A = (L L^T)^-1 : solve L Y = I, then L^T A = Y
@@ -387,7 +428,7 @@ __device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats,
 #pragma unroll
                     for (int k = 0; k < DM; ++k)
                         if (k < i) s -= Lc[i * DM + k] * y[k];
-                    y[i] = s / Lc[i * DM + i];
+                    y[i] = s * invL[i];
                 }
 #pragma unroll
             for (int ii = 0; ii < DM; ++ii) {
@@ -397,7 +438,7 @@ __device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats,
 #pragma unroll
                     for (int k = 0; k < DM; ++k)
                         if (k > i && k < d) s -= Lc[k * DM + i] * A[k * DM + c];
-                    A[i * DM + c] = s / Lc[i * DM + i];
+                    A[i * DM + c] = s * invL[i];
                 }
             }
         }
@@ -450,11 +491,11 @@ __device__ __forceinline__ void tica_grad_body(const double* __restrict__ stats,
                         for (int k = 0; k < DM; ++k)
                             if (k < d) g0 += K[i * DM + k] * T[k * DM + j];
                         const double Gt = -(T[i * DM + j] + T[j * DM + i]);  // -2 * sym(T)
-                        g_u[i * d + j] = 4.0 * g0 / Bg;                       // (2/B) G0, G0 = 2 K T
-                        g_v[i * d + j] = Gt / Bg;                             // (1/B) Gtau
+                        g_u[i * d + j] = 4.0 * g0 * invB;                     // (2/B) G0, G0 = 2 K T
+                        g_v[i * d + j] = Gt * invB;                           // (1/B) Gtau
                         cs += Gt * (ml[j] - mu[j]);
                     }
-                g_c[i] = -cs / Bg;
+                g_c[i] = -cs * invB;
             }
     }
     const int slot = *log_count;
@@ -496,6 +537,143 @@ static TicaGradFn tica_grad_fn(int d) {
     }
 }
 
+// tica_grad_body spread over the lanes of one wave (D <= 4: lane l < D*D owns matrix element (l / D, l % D)): the
+// single-thread form is a chain of ~2000 dependent float64 instructions (8 us); here every matrix product is one step
+// of D multiply-adds per lane and only the Cholesky factorisation (D columns) and the two triangular solves (one
+// column of the inverse per lane) stay sequential.  Matrices live in LDS; the wave is its own barrier.
+template <int D>
+struct TicaWaveLds {
+    double mu[D], ml[D], invL[D];
+    double C0[D * D], Ct[D * D], L[D * D], A[D * D], K[D * D], T[D * D];
+};
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int D>
+__device__ __forceinline__ void tica_grad_wave(TicaWaveLds<D>& w, const double* __restrict__ stats, double Bg, double reg,
+                                               double* __restrict__ gradp, double* __restrict__ log, int* __restrict__ log_count,
+                                               int log_cap, int log_width, int lane) {
+    const int i = lane / D, j = lane % D;
+    const bool el = lane < D * D;
+    const double invB = 1.0 / Bg;
+    const double* Stt = stats + 2 * D;
+    const double* Stl = stats + 2 * D + D * D;
+    if (lane < D) {
+        w.mu[lane] = stats[lane] * invB;
+        w.ml[lane] = stats[D + lane] * invB;
+    }
+    wave_sync_lds();
+    if (el) {
+        w.C0[lane] = 0.5 * (Stt[i * D + j] + Stt[j * D + i]) * invB - w.mu[i] * w.mu[j];
+        const double cij = Stl[i * D + j] * invB - w.mu[i] * w.ml[j];
+        const double cji = Stl[j * D + i] * invB - w.mu[j] * w.ml[i];
+        w.Ct[lane] = 0.5 * (cij + cji);
+        w.L[lane] = 0.0;
+    }
+    wave_sync_lds();
+    // Cholesky of C0 + reg I, column by column
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        if (lane == 0) {
+            double s = w.C0[k * D + k] + reg;
+#pragma unroll
+            for (int m = 0; m < D; ++m)
+                if (m < k) s -= w.L[k * D + m] * w.L[k * D + m];
+            const double lkk = sqrt(s);
+            w.L[k * D + k] = lkk;
+            w.invL[k] = s > 0.0 ? 1.0 / lkk : NAN;
+        }
+        wave_sync_lds();
+        if (lane < D && lane > k) {   // L[lane][k]
+            double s = w.C0[lane * D + k];
+#pragma unroll
+            for (int m = 0; m < D; ++m)
+                if (m < k) s -= w.L[lane * D + m] * w.L[k * D + m];
+            w.L[lane * D + k] = s * w.invL[k];
+        }
+        wave_sync_lds();
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) ok = ok && !(w.invL[k] != w.invL[k]);
+    // A = (L L^T)^-1: lane c < D solves L y = e_c, L^T a = y (column c of A)
+    if (lane < D) {
+        const int c = lane;
+        double y[D], a[D];
+#pragma unroll
+        for (int r = 0; r < D; ++r) {
+            double s = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < D; ++m)
+                if (m < r) s -= w.L[r * D + m] * y[m];
+            y[r] = s * w.invL[r];
+        }
+#pragma unroll
+        for (int rr = 0; rr < D; ++rr) {
+            const int r = D - 1 - rr;
+            double s = y[r];
+#pragma unroll
+            for (int m = 0; m < D; ++m)
+                if (m > r) s -= w.L[m * D + r] * a[m];
+            a[r] = s * w.invL[r];
+        }
+#pragma unroll
+        for (int r = 0; r < D; ++r) w.A[r * D + c] = a[r];
+    }
+    wave_sync_lds();
+    if (el) {   // K = A Ct
+        double s = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) s += w.A[i * D + m] * w.Ct[m * D + j];
+        w.K[lane] = s;
+    }
+    wave_sync_lds();
+    double Tij = 0.0;
+    if (el) {   // T = K A (= A Ct A)
+#pragma unroll
+        for (int m = 0; m < D; ++m) Tij += w.K[i * D + m] * w.A[m * D + j];
+        w.T[lane] = Tij;
+    }
+    wave_sync_lds();
+    if (gradp && el) {
+        double g0 = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) g0 += w.K[i * D + m] * w.T[m * D + j];
+        const double Gt = -(w.T[i * D + j] + w.T[j * D + i]);
+        gradp[D + lane] = 4.0 * g0 * invB;               // (2/B) G0, G0 = 2 K T
+        gradp[D + D * D + lane] = Gt * invB;             // (1/B) Gtau
+    }
+    if (gradp && lane < D) {
+        gradp[lane] = w.mu[lane];
+        double cs = 0.0;
+#pragma unroll
+        for (int m = 0; m < D; ++m) cs += -(w.T[lane * D + m] + w.T[m * D + lane]) * (w.ml[m] - w.mu[m]);
+        gradp[D + 2 * D * D + lane] = -cs * invB;
+    }
+    const int slot = *log_count;
+    if (slot < log_cap) {
+        double* rec = log + (int64_t)slot * log_width;
+        if (lane == 0) {
+            double loss = 0.0;   // -tr(K K), summed in the order of the single-thread form
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b < D; ++b) loss -= w.K[a * D + b] * w.K[b * D + a];
+            rec[0] = ok ? loss : NAN;
+            rec[1] = Bg;
+        }
+        if (el) {
+            rec[2 + lane] = w.C0[lane];
+            rec[2 + D * D + lane] = w.Ct[lane];
+        }
+        if (lane < D) rec[2 + 2 * D * D + lane] = w.mu[lane];
+    }
+    wave_sync_lds();
+    if (lane == 0) *log_count = slot + 1;
+}
+
 // The same statistics for D <= 4 outputs with every thread at work: a thread walks whole rows (its pair's
 // 2 D values, 2 D + 2 D^2 float64 accumulators in registers), waves combine by shuffles, the block through
 // LDS.  rows_per_block pairs per block (a multiple of 256; stats_plan): enough blocks to spread a small batch over
@@ -516,6 +694,7 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
                                                               double* __restrict__ out, FusedHead fused) {
     constexpr int W = 2 * D + 2 * D * D;
     __shared__ double red[4][W];
+    __shared__ TicaWaveLds<D> s_head;
     __shared__ unsigned s_last;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double acc[W];
@@ -541,11 +720,17 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
             }
         }
     }
+    // wave reduction as a butterfly reduce-scatter: every step halves the values a lane carries (W = 40 -> 20 -> 10 -> 5,
+    // then three all-reduce steps): ~50 float64 shuffles per lane in independent chains instead of 6 W = 240 dependent
+    // ones (a float64 shuffle is two ds_bpermute round trips: the plain form spent 14 us of latency here)
+    {
+        int base = 0, dup = 0;
+        const int cnt = butterfly_sum<W, 32, W, double>(acc, lane, base, dup);
+        if ((lane & dup) == 0) {
 #pragma unroll
-    for (int o = 0; o < W; ++o) {
-        double v = acc[o];
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-        if (lane == 0) red[wave][o] = v;
+            for (int i = 0; i < W; ++i)
+                if (i < cnt) red[wave][base + i] = acc[i];
+        }
     }
     __syncthreads();
     if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
@@ -566,7 +751,8 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
         if (t == 0) *ticket = 0u;
         if (fused.on) {
             __syncthreads();
-            if (t == 0) tica_grad_body<D>(&red[0][0], D, fused.Bg, fused.reg, fused.gradp, fused.log, fused.log_count, fused.log_cap, fused.log_width);
+            if (wave == 0)
+                tica_grad_wave<D>(s_head, &red[0][0], fused.Bg, fused.reg, fused.gradp, fused.log, fused.log_count, fused.log_cap, fused.log_width, lane);
         }
     }
 }
@@ -1531,8 +1717,22 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     }
     OptArgs oa{};
     if (fuse_opt) oa = next_opt_args(m);
-    hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params, m->adam_m,
-                       m->adam_v, m->opt_aux, oa);
+    int max_splits = 0, max_bblocks = 0;
+    int64_t max_total = 0;
+    for (int l = 0; l < L; ++l) {
+        if (ra.l[l].splits > max_splits) max_splits = ra.l[l].splits;
+        if (ra.l[l].bblocks > max_bblocks) max_bblocks = ra.l[l].bblocks;
+        if (ra.l[l].w_count + ra.l[l].out > max_total) max_total = ra.l[l].w_count + ra.l[l].out;
+    }
+    if (max_splits <= 512 && max_bblocks <= 1024) {   // few partials per weight (the few bias elements may see more)
+        int64_t bx = cdiv(max_total, 64);
+        if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(reduce_grads_small_kernel, dim3((unsigned)bx, L), dim3(256), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params,
+                           m->adam_m, m->adam_v, m->opt_aux, oa);
+    } else {
+        hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params, m->adam_m,
+                           m->adam_v, m->opt_aux, oa);
+    }
     DCV_CHECK_LAUNCH();
     if (m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
     return DCV_OK;

@@ -502,10 +502,16 @@ class LinearCalculator(CVCalculator):
         text += "\n# Collective variable\n"
         for i in range(self.cv.shape[1]):
             text += plumed_combine(f"{self.cv_name}_{i}", normalized, self.cv[:, i])
-        # reference: offset = (min + max) / 2, scale = 2 / (max - min) -- the same numbers as cv_norm_mean and
-        # 1 / cv_norm_range (halving is exact), which a model loaded from model.zip also carries
-        offset = np.asarray(self.cv_norm_mean, dtype=np.float64)
-        scale = 1.0 / np.asarray(self.cv_norm_range, dtype=np.float64)
+        # reference assembler.py:367-370: offset = (min + max) / 2, scale = 2 / (max - min) from cv_stats, in the float32 of
+        # the pandas min / max they come from (the '%.17g' text shows every bit); a model loaded from model.zip carries
+        # the same two numbers as cv_norm_mean / cv_norm_range
+        if self.cv_stats:
+            cmin, cmax = np.asarray(self.cv_stats["min"], dtype=np.float32), np.asarray(self.cv_stats["max"], dtype=np.float32)
+        else:
+            cmin = np.asarray(self.cv_norm_mean, dtype=np.float32) - np.asarray(self.cv_norm_range, dtype=np.float32)
+            cmax = np.asarray(self.cv_norm_mean, dtype=np.float32) + np.asarray(self.cv_norm_range, dtype=np.float32)
+        offset = (cmin + cmax) / 2
+        scale = 2 / (cmax - cmin)
         text += "\n# Normalized Collective variable\n"
         for i in range(self.cv.shape[1]):
             text += plumed_combine(f"norm_{self.cv_name}_{i}", [f"{self.cv_name}_{i}"], [scale[i]], [offset[i]])

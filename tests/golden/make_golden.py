@@ -17,7 +17,11 @@ What is stored is *data* (inputs and expected outputs), never reference source:
   outputs of the reference's importable ``statistics`` module (hierarchical as in its tests,
   and k-means, which the reference's tests do not pin) on those CSVs and on seeded
   synthetic sets;
-* ``schema_defaults.json``  model_dump() of the reference's pydantic schemas for this path.
+* ``schema_defaults.json``  model_dump() of the reference's pydantic schemas for this path;
+* ``plumed_text.json``      PLUMED input text produced by the reference's own ``modules/plumed/command.py`` (loaded
+  standalone with importlib: it needs only the standard library and NumPy) for the CV section the assembler writes
+  (``plumed/input/assembler.py:333-431``: the comment lines are its literals) on the arrays of ``pca_model.zip`` and for
+  a PYTORCH_MODEL CV, plus single COMBINE / PRINT lines.
 """
 import io
 import json
@@ -140,6 +144,43 @@ def main():
     with open(os.path.join(OUT, "schema_defaults.json"), "w") as f:
         json.dump({"train_colvars": TrainColvarsSchema().model_dump(),
                    "traj_cluster": TrajClusterSchema().model_dump()}, f, indent=1, sort_keys=True)
+    # ------------------------------------------------------------------ PLUMED text
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_plumed_command", os.path.join(REF, "deep_cartograph", "modules", "plumed", "command.py"))
+    cmd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cmd)
+    text = {}
+    text["combine_basic"] = cmd.combine("feat_0", ["d1"], [1 / 0.25], [0.1])
+    text["combine_weights"] = cmd.combine("pca_1", ["feat_0", "feat_1"], np.array([0.5, -1 / 3]))
+    text["combine_periodic"] = cmd.combine("c", ["a"], periodic=True)
+    text["combine_float32"] = cmd.combine("t", ["a", "b"], np.array([0.1, -2.5e-7], dtype=np.float32), np.array([3.0, 1e10], dtype=np.float32))
+    text["print"] = cmd.print(["norm_pca_0", "norm_pca_1"], "pca_out.dat", 1)
+    text["print_stride"] = cmd.print(["deep_tica.node-0"], "out/colvar.dat", 500, fmt="%.6f")
+    text["pytorch_model"] = cmd.pytorch_model("deep_tica", feats[:5], "/abs/path/deep_tica_weights.pt")
+    # the linear CV section as assembler.add_linear_cv composes it, on the arrays of pca_model.zip; cv_stats in float32 as
+    # LinearCalculator.normalize_cv leaves them (min = mean - range, max = mean + range of the stored normalisation)
+    fm, fr = lin["pca.features_norm_mean"], lin["pca.features_norm_range"]
+    W = lin["pca.cv_weights"]
+    cmin = (lin["pca.cv_norm_mean"] - lin["pca.cv_norm_range"]).astype(np.float32)
+    cmax = (lin["pca.cv_norm_mean"] + lin["pca.cv_norm_range"]).astype(np.float32)
+    sec = "\n# Normalized features\n"
+    labels = []
+    for i, f_ in enumerate(feats):
+        sec += cmd.combine(f"feat_{i}", [f_], [1 / fr[i]], [fm[i]])
+        labels.append(f"feat_{i}")
+    sec += "\n# Collective variable\n"
+    for i in range(W.shape[1]):
+        sec += cmd.combine(f"pca_{i}", labels, W[:, i])
+    off, sc = (cmin + cmax) / 2, 2 / (cmax - cmin)
+    sec += "\n# Normalized Collective variable\n"
+    for i in range(W.shape[1]):
+        sec += cmd.combine(f"norm_pca_{i}", [f"pca_{i}"], [sc[i]], [off[i]])
+    text["linear_cv_section_pca"] = sec
+    text["linear_cv_stats_min"] = [float(v) for v in cmin]
+    text["linear_cv_stats_max"] = [float(v) for v in cmax]
+    with open(os.path.join(OUT, "plumed_text.json"), "w") as f:
+        json.dump(text, f, indent=1, sort_keys=True)
     print("golden fixtures written to", OUT)
 
 

@@ -251,16 +251,65 @@ def test_parallel_text_parse_matches_serial(tmp_path):
     assert kept == names[1:]
 
 
-def test_plumed_command_text():
-    """COMBINE / PRINT lines in the reference's text format (plumed/command.py:357-420, 520-564: %.17g coefficients and
-    parameters, PERIODIC keyword, trailing newline).  Expected strings written out by hand from that format."""
-    from deep_cartograph_amd.cv_calculator import plumed_combine, plumed_print
+def test_plumed_text_matches_reference_command_module():
+    """COMBINE / PRINT / PYTORCH_MODEL lines and the whole linear-CV section against text produced by the reference's
+    own modules/plumed/command.py (tests/golden/plumed_text.json, generated by make_golden.py)."""
+    import json
 
-    assert plumed_combine("feat_0", ["d1"], [1 / 0.25], [0.1]) == "feat_0: COMBINE ARG=d1 COEFFICIENTS=4 PARAMETERS=0.10000000000000001 PERIODIC=NO\n"
-    assert plumed_combine("pca_1", ["feat_0", "feat_1"], np.array([0.5, -1 / 3])) == \
-        "pca_1: COMBINE ARG=feat_0,feat_1 COEFFICIENTS=0.5,-0.33333333333333331 PERIODIC=NO\n"
-    assert plumed_combine("c", ["a"], periodic=True) == "c: COMBINE ARG=a PERIODIC=YES\n"
-    assert plumed_print(["norm_pca_0", "norm_pca_1"], "pca_out.dat", 1) == "PRINT ARG=norm_pca_0,norm_pca_1 FILE=pca_out.dat STRIDE=1 FMT=%.4f\n"
+    from deep_cartograph_amd.cv_calculator import cv_calculators_map, plumed_combine, plumed_print
+    from tests.conftest import GOLDEN, load_golden
+
+    t = json.load(open(os.path.join(GOLDEN, "plumed_text.json")))
+    assert plumed_combine("feat_0", ["d1"], [1 / 0.25], [0.1]) == t["combine_basic"]
+    assert plumed_combine("pca_1", ["feat_0", "feat_1"], np.array([0.5, -1 / 3])) == t["combine_weights"]
+    assert plumed_combine("c", ["a"], periodic=True) == t["combine_periodic"]
+    assert plumed_combine("t", ["a", "b"], np.array([0.1, -2.5e-7], dtype=np.float32), np.array([3.0, 1e10], dtype=np.float32)) == t["combine_float32"]
+    assert plumed_print(["norm_pca_0", "norm_pca_1"], "pca_out.dat", 1) == t["print"]
+    assert plumed_print(["deep_tica.node-0"], "out/colvar.dat", 500, fmt="%.6f") == t["print_stride"]
+    # the linear CV section on the arrays of the reference's pca_model.zip
+    lin = load_golden("linear_models.npz")
+    names = [str(s) for s in load_golden("features_164x54.npz")["names"]]
+    calc = cv_calculators_map["pca"]({"dimension": 2, "features_normalization": "mean_std"}, "/tmp/x")
+    calc.features_ref_labels = names
+    calc.features_norm_mean, calc.features_norm_range = lin["pca.features_norm_mean"], lin["pca.features_norm_range"]
+    calc.cv = lin["pca.cv_weights"]
+    calc.cv_stats = {"min": np.array(t["linear_cv_stats_min"], dtype=np.float32), "max": np.array(t["linear_cv_stats_max"], dtype=np.float32)}
+    assert calc.plumed_cv_lines() == t["linear_cv_section_pca"]
+    assert calc.plumed_cv_labels() == ["norm_pca_0", "norm_pca_1"]
+    # neural CVs: PYTORCH_MODEL line
+    nn = cv_calculators_map["deep_tica"]({"dimension": 2}, "/tmp/x")
+    nn.features_ref_labels = names[:5]
+    nn.weights_path = "/abs/path/deep_tica_weights.pt"
+    assert nn.plumed_cv_lines() == "\n# Collective variable\n" + t["pytorch_model"]
+
+
+def test_read_torchscript_decomposes_the_reference_model_files():
+    """export.read_torchscript on the reference's real deep_tica_model.zip / ae_model.zip (build container only: the files
+    never travel): layers, activations and buffers come out as the arrays captured in nn_models.npz."""
+    import io
+    import tempfile
+    import zipfile
+
+    from deep_cartograph_amd import export
+    from tests.conftest import load_golden
+
+    base = "/root/reference/deep_cartograph/tests/data/input/models"
+    if not os.path.isdir(base):
+        pytest.skip("reference not present (GPU box)")
+    g = load_golden("nn_models.npz")
+    for cv, prefix in (("deep_tica", "nn.nn"), ("ae", "encoder.nn")):
+        with zipfile.ZipFile(os.path.join(base, f"{cv}_model.zip")) as z, tempfile.NamedTemporaryFile(suffix=".pt") as f:
+            f.write(z.read("model/cv_weights.pt"))
+            f.flush()
+            parts = export.read_torchscript(f.name)
+        assert parts["kind"] == cv and parts["acts"] == ["leaky_relu", "leaky_relu", None]
+        for (w, b), i in zip(parts["linears"], (0, 3, 6)):
+            np.testing.assert_array_equal(w, g[f"{cv}.param.{prefix}.{i}.weight"])
+            np.testing.assert_array_equal(b, g[f"{cv}.param.{prefix}.{i}.bias"])
+        np.testing.assert_array_equal(parts["norm_in"][0], g[f"{cv}.buffer.norm_in.mean"])
+        np.testing.assert_array_equal(parts["postprocessing"][1], g[f"{cv}.buffer.postprocessing.range"])
+        if cv == "deep_tica":
+            np.testing.assert_array_equal(parts["tica"][1], g["deep_tica.buffer.tica.evecs"])
 
 
 def test_calculators_refuse_cpu():

@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 
 using namespace dcv;
 
@@ -24,6 +25,25 @@ static double time_ms(F f, int iters) {
     float ms;
     CK(hipEventElapsedTime(&ms, a, b));
     return ms / iters;
+}
+
+// GPU-side duration of single launches: an event pair around each launch, launches separated by a host sync
+template <class F>
+static double time_ms_single(F f, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    double tot = 0;
+    for (int i = 0; i < iters; ++i) {
+        CK(hipEventRecord(a, 0));
+        f();
+        CK(hipEventRecord(b, 0));
+        CK(hipEventSynchronize(b));
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        tot += ms;
+    }
+    return tot / iters;
 }
 
 #ifdef DCV_STAMP
@@ -98,6 +118,13 @@ int main(int argc, char** argv) {
         EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};
         double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, it);
         printf("L0 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);
+        double ms1 = time_ms_single([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, 20);
+        auto t0 = std::chrono::high_resolution_clock::now();
+        for (int i = 0; i < 200; ++i) launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s);
+        auto t1 = std::chrono::high_resolution_clock::now();
+        CK(hipDeviceSynchronize());
+        printf("L0 fwd   single launch between events %8.1f us ; host time per enqueue (200 back-to-back) %6.1f us\n", ms1 * 1e3,
+               std::chrono::duration<double, std::micro>(t1 - t0).count() / 200);
         dump_stamps("L0 fwd", (int)(R / 128 * 2 > 0 ? R / 128 * 2 : 1));
     }
     {   // L0 wgrad: dZ[R,256]^T x X[R,512], split

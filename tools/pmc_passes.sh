@@ -7,8 +7,8 @@ TAG="${1:-r01}"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-STATS_ARGS="${STATS_ARGS:---steps 61 --warmup 5 --no-cpu-baseline --alt-batch 0 --other-mode-steps 0}"
-ARGS="${BENCH_ARGS:---steps 61 --warmup 5 --no-cpu-baseline --alt-batch 0 --other-mode-steps 0 --frames 5000000}"
+STATS_ARGS="${STATS_ARGS:---batch 524208 --steps 61 --warmup 5 --no-cpu-baseline --large-batch 0 --other-mode-steps 0}"
+ARGS="${BENCH_ARGS:---batch 524208 --steps 61 --warmup 5 --no-cpu-baseline --large-batch 0 --other-mode-steps 0 --frames 5000000}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python bench.py $STATS_ARGS > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 echo "stats exit $?"
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv

@@ -14,7 +14,7 @@ for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
-adam = [i for i, r in enumerate(rows) if "reduce_grads_kernel" in r[2]]   # one per optimiser step (the update is fused into it)
+adam = [i for i, r in enumerate(rows) if "reduce_grads" in r[2]]   # one per optimiser step (the update is fused into it)
 lo, hi = adam[-nsteps - 1], adam[-1]
 win = rows[lo + 1: hi + 1]
 span = win[-1][1] - win[0][0]

@@ -99,6 +99,9 @@ SIGNATURES = {
     "dcv_mlp_input_sensitivity": (C.c_int, [_P, _P, _I64, _I64, _P, _P, _P, _P, _SZ, _P]),
     "dcv_kmeans_workspace": (_SZ, [_I64, _I32, _I32]),
     "dcv_kmeans_step": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "dcv_kmeanspp_workspace": (_SZ, [_I64, _I32]),
+    "dcv_kmeanspp_potentials": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
+    "dcv_kmeanspp_update": (C.c_int, [_P, _I64, _I32, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
     "dcv_set_gemm_mode": (C.c_int, [C.c_int]),
     "dcv_get_gemm_mode": (C.c_int, []),
     "dcv_label_stats_workspace": (_SZ, [_I64, _I32, _I32]),

@@ -40,7 +40,15 @@ __global__ void cov_reduce_kernel(const float* __restrict__ slab, int64_t splits
     if (i >= FF) return;
     for (int w = 0; w < nb; ++w) {
         double acc = 0.0;
-        for (int64_t z = 0; z < splits; ++z) acc += (double)slab[(z * nb + w) * FF + i];
+        int64_t z = 0;
+        for (; z + 8 <= splits; z += 8) {   // eight independent loads in flight, added in chunk order (same sum as a serial walk)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = slab[((z + u) * nb + w) * FF + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += (double)v[u];
+        }
+        for (; z < splits; ++z) acc += (double)slab[(z * nb + w) * FF + i];
         (w == 0 ? outA : outB)[i] = acc;
     }
     if (nb == 1) outB[i] = 0.0;

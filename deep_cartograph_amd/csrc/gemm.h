@@ -304,7 +304,7 @@ struct KMajorStage {
     unsigned okmask;    // units of the LAST register load that were in range
     int ncol;           // how many of the 4 columns are in range (0..4)
     bool has_shift;
-    bool all_cols;      // every column of the tile in range, 16-byte loads, no shift (workgroup-uniform)
+    bool all_cols;      // every column of the tile in range, 16-byte loads (workgroup-uniform)
     bool affine;        // no gather and a leading dimension the 32-bit unit offsets cover
     unsigned voff[PER]; // byte offset of unit i from (first row of the stage, first column of the tile)
 
@@ -322,7 +322,7 @@ struct KMajorStage {
             if (ncol > 2) sh.z = op.shift[col + 2];
             if (ncol > 3) sh.w = op.shift[col + 3];
         }
-        all_cols = VEC && (UNITS % 256 == 0) && !has_shift && (c0 + T <= c_end);
+        all_cols = VEC && (UNITS % 256 == 0) && (c0 + T <= c_end);   // a shift is subtracted at store time (register path) or on the fragments (DMA path)
         affine = !GATHER && op.ld < kMaxAffineLd;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
@@ -607,7 +607,37 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         v4f a[FM];
         v4f b[NB][FN];
     };
-    auto read_frags = [&](Frags& f, const float* la, const float* lb, int g) {
+    // Column shift of KMAJOR operands (covariances: z = x - shift).  The register-staged loop subtracts it when a stage
+    // is stored to LDS; a stage filled by LDS-DMA holds the raw values, and the shift -- one constant per lane and
+    // fragment, since a lane always reads the same column -- comes off the fragments instead (`sub`): the same float32
+    // subtraction either way, one v_sub per fragment element against 64-cycle MFMAs.
+    float sha[FM], shb[FN];
+    bool dma_sub = false;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) sha[i] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) shb[j] = 0.f;
+    if constexpr (!A_MM) {
+        if (A.shift) {
+            dma_sub = true;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int64_t c = m0 + wm + i * 32 + (lane & 31);
+                sha[i] = c < d.M ? A.shift[c] : 0.f;
+            }
+        }
+    }
+    if constexpr (!B_MM) {
+        if (B.shift) {
+            dma_sub = true;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int64_t c = n0 + wn + j * 32 + (lane & 31);
+                shb[j] = c < d.N ? B.shift[c] : 0.f;
+            }
+        }
+    }
+    auto read_frags = [&](Frags& f, const float* la, const float* lb, int g, bool sub = false) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             if constexpr (A_MM) {
@@ -615,6 +645,10 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) f.a[i][s] = frag_kmajor<TM>(la, wm + i * 32, g, s, lane);
+                if (sub) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) f.a[i][s] -= sha[i];
+                }
             }
         }
 #pragma unroll
@@ -626,6 +660,10 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) f.b[b][j][s] = frag_kmajor<TN>(lb + b * B_SZ, wn + j * 32, g, s, lane);
+                    if (sub) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) f.b[b][j][s] -= shb[j];
+                    }
                 }
             }
     };
@@ -953,7 +991,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             __syncthreads();   // last stage fully read before the buffers are reused
         } else {
         Frags f0, f1;
-        read_frags(f0, lds, lds + A_SZ, 0);
+        read_frags(f0, lds, lds + A_SZ, 0, dma_sub);
         int cur_buf = 0;
         for (int64_t st = 0; st < nst; ++st) {
             const float* la = lds + cur_buf * STAGE;
@@ -961,13 +999,13 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             const int nxt_buf = cur_buf + 1 == NBUF ? 0 : cur_buf + 1;
 #pragma unroll
             for (int g = 0; g < G; g += 2) {
-                read_frags(f1, la, lb, g + 1);
+                read_frags(f1, la, lb, g + 1, dma_sub);
                 __builtin_amdgcn_sched_barrier(0);
                 pin_frags(f0);
                 mfma_group(f0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 2 < G) {
-                    read_frags(f0, la, lb, g + 2);
+                    read_frags(f0, la, lb, g + 2, dma_sub);
                     __builtin_amdgcn_sched_barrier(0);
                     pin_frags(f1);
                     mfma_group(f1);
@@ -996,7 +1034,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_step(f1, 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    read_frags(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
+                    read_frags(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0, dma_sub);
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_step(f1, 3);
                     __builtin_amdgcn_sched_barrier(0);

@@ -4,7 +4,8 @@
 //
 // Determinism: every wave owns a private LDS accumulator, waves are combined in wave order,
 // blocks in block order, and each thread walks its points in increasing index order.
-#include "common.h"
+#include "gemm_kernels.h"   // butterfly_sum
+#include <stdlib.h>
 
 namespace dcv {
 
@@ -125,12 +126,285 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_kernel(const double* _
     }
 }
 
-__global__ void kmeans_final_kernel(const double* __restrict__ part, int nblocks, int width, double* __restrict__ acc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width) return;
+// The same pass for the common small shapes (D <= 4 coordinates, k <= KMAX <= 16 clusters) without a single atomic:
+// every thread keeps the sums and counts of all clusters in registers (a predicated add per cluster and coordinate;
+// the LDS float64 atomics of the general kernel serialise on the few hot addresses and held it to 1.2 TB/s), waves
+// combine with a butterfly reduce-scatter, then wave order, then block order.  Streams 8 D + 8 bytes per point.
+template <int D, int KMAX>
+__global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const double* __restrict__ P, int64_t n,
+                                                                     const double* __restrict__ offset,
+                                                                     const double* __restrict__ centers, int k,
+                                                                     int32_t* __restrict__ labels, double* __restrict__ mindist,
+                                                                     double* __restrict__ part) {
+    constexpr int WR = KMAX * D + KMAX + 2;   // sums | counts | inertia | changed
+    __shared__ double s_c[KMAX * D];
+    __shared__ double s_cn[KMAX];
+    __shared__ double s_red[4][WR];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double off[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) off[c] = offset ? offset[c] : 0.0;
+    for (int i = t; i < KMAX * D; i += kKmThreads) s_c[i] = i < k * D ? centers[i] : 0.0;
+    __syncthreads();
+    if (t < KMAX) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) s += s_c[t * D + c] * s_c[t * D + c];
+        s_cn[t] = s;
+    }
+    __syncthreads();
+    double acc[WR];
+#pragma unroll
+    for (int i = 0; i < WR; ++i) acc[i] = 0.0;
+    const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t begin = (int64_t)blockIdx.x * per_block;
+    const int64_t end = begin + per_block < n ? begin + per_block : n;
+    // U points per thread are requested before any of them is used: with one point per thread in flight a wave keeps
+    // 2 KB outstanding and the pass is bound by load latency (1.4 TB/s), not by HBM
+    constexpr int U = 4;
+    for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)kKmThreads * U) {
+        double xs[U][D];
+        int32_t olds[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kKmThreads;
+            if (i < end) {
+                const double* p = P + i * D;
+                if constexpr (D % 2 == 0) {
+#pragma unroll
+                    for (int c = 0; c < D; c += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(p + c);
+                        xs[u][c] = v.x;
+                        xs[u][c + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) xs[u][c] = p[c];
+                }
+                olds[u] = labels[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kKmThreads;
+            if (i >= end) break;
+            double x[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) x[c] = xs[u][c] - off[c];   // X -= X_mean, as KMeans.fit does (a zero offset changes nothing)
+            const int32_t old = olds[u];
+            int best = 0;
+            double bestv = INFINITY;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                if (j < k) {
+                    double dot = 0.0;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) dot += x[c] * s_c[j * D + c];
+                    const double v = s_cn[j] - 2.0 * dot;
+                    if (v < bestv) {   // first minimum wins (sklearn lloyd_iter_chunked_dense)
+                        bestv = v;
+                        best = j;
+                    }
+                }
+            }
+            double dist = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                const double df = x[c] - s_c[best * D + c];
+                dist += df * df;
+            }
+            acc[KMAX * D + KMAX] += dist;
+            if (mindist) mindist[i] = dist;
+            if (old != best) acc[KMAX * D + KMAX + 1] += 1.0;
+            labels[i] = best;
+#pragma unroll
+            for (int j = 0; j < KMAX; ++j) {
+                const bool mine = best == j;
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[j * D + c] += mine ? x[c] : 0.0;
+                acc[KMAX * D + j] += mine ? 1.0 : 0.0;
+            }
+        }
+    }
+    {
+        int base = 0, dup = 0;
+        const int cnt = butterfly_sum<WR, 32, WR, double>(acc, lane, base, dup);
+        if ((lane & dup) == 0) {
+#pragma unroll
+            for (int i = 0; i < WR; ++i)
+                if (i < cnt) s_red[wave][base + i] = acc[i];
+        }
+    }
+    __syncthreads();
+    // output layout of the general kernel: [sums k*d | counts k | inertia | changed]
+    double* my_part = part + (int64_t)blockIdx.x * (k * D + k + 2);
+    for (int i = t; i < k * D + k + 2; i += kKmThreads) {
+        const int src = i < k * D ? i : (i < k * D + k ? KMAX * D + (i - k * D) : KMAX * D + KMAX + (i - k * D - k));
+        my_part[i] = ((s_red[0][src] + s_red[1][src]) + s_red[2][src]) + s_red[3][src];
+    }
+}
+typedef void (*km_reg_fn_t)(const double*, int64_t, const double*, const double*, int, int32_t*, double*, double*);
+static km_reg_fn_t km_reg_fn(int d, int k) {
+    if (k <= 8) {
+        switch (d) {
+            case 1: return kmeans_step_reg_kernel<1, 8>;
+            case 2: return kmeans_step_reg_kernel<2, 8>;
+            case 3: return kmeans_step_reg_kernel<3, 8>;
+            case 4: return kmeans_step_reg_kernel<4, 8>;
+            default: return nullptr;
+        }
+    }
+    if (k <= 16) {
+        switch (d) {
+            case 1: return kmeans_step_reg_kernel<1, 16>;
+            case 2: return kmeans_step_reg_kernel<2, 16>;
+            case 3: return kmeans_step_reg_kernel<3, 16>;
+            case 4: return kmeans_step_reg_kernel<4, 16>;
+            default: return nullptr;
+        }
+    }
+    return nullptr;
+}
+
+// acc[i] = sum over the blocks of part[b][i]: one workgroup per output, its threads take b = t, t + 256, ... (all loads
+// in flight at once; one thread walking 1024 partials with dependent loads cost 0.4 ms -- most of the pass) and a fixed
+// LDS tree adds them up.
+__global__ __launch_bounds__(256) void kmeans_final_kernel(const double* __restrict__ part, int nblocks, int width, double* __restrict__ acc) {
+    __shared__ double s_red[256];
+    const int i = blockIdx.x, t = threadIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * width + i];
-    acc[i] = s;
+    for (int b = t; b < nblocks; b += 256) s += part[(int64_t)b * width + i];
+    s_red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) s_red[t] += s_red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) acc[i] = s_red[0];
+}
+
+// ------------------------------------------------------------------ k-means++ seeding passes
+// sklearn _kmeans_plusplus keeps, per point, the squared distance to the closest centre
+// chosen so far and, for every new centre, scores a few candidates by the potential sum_i min(closest_i, dist(x_i, cand)).
+// Both are streaming passes over the resident points; only the sequential float64 cumsum + searchsorted that turns the
+// random draws into candidate indices stays on the host (a parallel prefix sum rounds differently).
+// dist = -2 x.c + |c|^2 + |x|^2, clipped at 0 (sklearn euclidean_distances(squared=True) with precomputed norms), every
+// step separately rounded.
+constexpr int kPpMaxTrials = 8;
+template <int D>
+__device__ __forceinline__ double pp_dist(const double (&x)[D], const double* __restrict__ c, double cc) {
+    double dot = 0.0, xx = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+        dot = fma(x[q], c[q], dot);
+        xx = fma(x[q], x[q], xx);
+    }
+    const double v = __dadd_rn(__dadd_rn(__dmul_rn(-2.0, dot), cc), xx);
+    return v > 0.0 ? v : 0.0;
+}
+template <int D>
+__device__ __forceinline__ void pp_load(const double* __restrict__ P, int64_t i, const double* off, double (&x)[D]) {
+    const double* p = P + i * D;
+    if constexpr (D % 2 == 0) {
+#pragma unroll
+        for (int c = 0; c < D; c += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(p + c);
+            x[c] = v.x - off[c];
+            x[c + 1] = v.y - off[c + 1];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = p[c] - off[c];
+    }
+}
+// part[block][t] = sum over the block's points of min(closest_i, dist(x_i, cand_t))
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeanspp_potentials_kernel(const double* __restrict__ P, int64_t n,
+                                                                         const double* __restrict__ offset,
+                                                                         const double* __restrict__ cand, int T,
+                                                                         const double* __restrict__ closest, double* __restrict__ part) {
+    __shared__ double s_c[kPpMaxTrials * D];
+    __shared__ double s_cc[kPpMaxTrials];
+    __shared__ double s_red[kKmThreads];
+    const int t = threadIdx.x;
+    double off[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) off[c] = offset ? offset[c] : 0.0;
+    if (t < T * D) s_c[t] = cand[t];
+    __syncthreads();
+    if (t < T) {
+        double s = 0.0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) s = fma(s_c[t * D + c], s_c[t * D + c], s);
+        s_cc[t] = s;
+    }
+    __syncthreads();
+    double acc[kPpMaxTrials];
+#pragma unroll
+    for (int q = 0; q < kPpMaxTrials; ++q) acc[q] = 0.0;
+    const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t begin = (int64_t)blockIdx.x * per_block;
+    const int64_t end = begin + per_block < n ? begin + per_block : n;
+    for (int64_t i = begin + t; i < end; i += kKmThreads) {
+        double x[D];
+        pp_load<D>(P, i, off, x);
+        const double cl = closest[i];
+#pragma unroll
+        for (int q = 0; q < kPpMaxTrials; ++q)
+            if (q < T) {
+                const double v = pp_dist<D>(x, s_c + q * D, s_cc[q]);
+                acc[q] += v < cl ? v : cl;
+            }
+    }
+    for (int q = 0; q < T; ++q) {
+        s_red[t] = acc[q];
+        __syncthreads();
+        for (int o = kKmThreads / 2; o > 0; o >>= 1) {
+            if (t < o) s_red[t] += s_red[t + o];
+            __syncthreads();
+        }
+        if (t == 0) part[(int64_t)blockIdx.x * T + q] = s_red[0];
+        __syncthreads();
+    }
+}
+// closest_i = first ? dist(x_i, c) : min(closest_i, dist(x_i, c)) ; part[block] = sum of the new values
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void kmeanspp_update_kernel(const double* __restrict__ P, int64_t n,
+                                                                     const double* __restrict__ offset,
+                                                                     const double* __restrict__ centre, int first,
+                                                                     double* __restrict__ closest, double* __restrict__ part) {
+    __shared__ double s_red[kKmThreads];
+    const int t = threadIdx.x;
+    double off[D], c[D];
+    double cc = 0.0;
+#pragma unroll
+    for (int q = 0; q < D; ++q) {
+        off[q] = offset ? offset[q] : 0.0;
+        c[q] = centre[q];
+        cc = fma(c[q], c[q], cc);
+    }
+    double acc = 0.0;
+    const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t begin = (int64_t)blockIdx.x * per_block;
+    const int64_t end = begin + per_block < n ? begin + per_block : n;
+    for (int64_t i = begin + t; i < end; i += kKmThreads) {
+        double x[D];
+        pp_load<D>(P, i, off, x);
+        double v = pp_dist<D>(x, c, cc);
+        if (!first) {
+            const double cl = closest[i];
+            v = v < cl ? v : cl;
+        }
+        closest[i] = v;
+        acc += v;
+    }
+    s_red[t] = acc;
+    __syncthreads();
+    for (int o = kKmThreads / 2; o > 0; o >>= 1) {
+        if (t < o) s_red[t] += s_red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) part[blockIdx.x] = s_red[0];
 }
 
 // ------------------------------------------------------------------ nearest sample per centroid
@@ -290,9 +564,13 @@ extern "C" int dcv_kmeans_step(const double* P_d, int64_t n, int32_t d, const do
     const int W = k * d + k;
     const size_t lds = ((size_t)k * d + k + 4 * W + 2 * kKmThreads) * sizeof(double);
     double* part = static_cast<double*>(ws_d);
-    hipLaunchKernelGGL(kmeans_step_kernel, dim3(nb), dim3(kKmThreads), lds, s, P_d, n, d, offset_d, centers_d, k, labels_d, mindist_d, part);
+    static const bool no_reg = [] { const char* e = getenv("DCV_KMEANS_ATOMIC"); return e && e[0] == '1'; }();   // diagnostic: general kernel
+    if (km_reg_fn_t reg = no_reg ? nullptr : km_reg_fn(d, k))
+        hipLaunchKernelGGL(reg, dim3(nb), dim3(kKmThreads), 0, s, P_d, n, offset_d, centers_d, (int)k, labels_d, mindist_d, part);
+    else
+        hipLaunchKernelGGL(kmeans_step_kernel, dim3(nb), dim3(kKmThreads), lds, s, P_d, n, d, offset_d, centers_d, k, labels_d, mindist_d, part);
     DCV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(kmeans_final_kernel, dim3((W + 2 + 255) / 256), dim3(256), 0, s, part, nb, W + 2, acc_d);
+    hipLaunchKernelGGL(kmeans_final_kernel, dim3(W + 2), dim3(256), 0, s, part, nb, W + 2, acc_d);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }
@@ -327,6 +605,54 @@ extern "C" int dcv_nearest_point(const double* train_d, int64_t n_train, const d
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(nearest_point_kernel, dim3((unsigned)cdiv(n_sup, kKmThreads)), dim3(kKmThreads),
                        (size_t)kKmThreads * d * sizeof(double), s, train_d, n_train, sup_d, n_sup, d, nn_d);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+// ------------------------------------------------------------------ k-means++ seeding (C-ABI)
+#define DCV_PP_DISPATCH(KERNEL, ...)                                                                   \
+    switch (d) {                                                                                      \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                    \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                    \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, __VA_ARGS__); break;                                    \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                    \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                    \
+        case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                                    \
+        case 7: hipLaunchKernelGGL(KERNEL<7>, __VA_ARGS__); break;                                    \
+        case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                    \
+        default: set_error("k-means++ passes: d=%d (1..8) unsupported", d); return DCV_EINVAL;        \
+    }
+
+extern "C" size_t dcv_kmeanspp_workspace(int64_t n, int32_t trials) {
+    if (n <= 0 || trials <= 0) return 0;
+    return (size_t)kKmMaxBlocks * (size_t)(trials > 1 ? trials : 1) * sizeof(double);
+}
+
+extern "C" int dcv_kmeanspp_potentials(const double* P_d, int64_t n, int32_t d, const double* offset_d, const double* cand_d,
+                                       int32_t trials, const double* closest_d, double* pot_d, void* ws_d, size_t ws_bytes, void* stream) {
+    DCV_REQUIRE(P_d && cand_d && closest_d && pot_d && n > 0, "dcv_kmeanspp_potentials: bad arguments");
+    DCV_REQUIRE(trials >= 1 && trials <= kPpMaxTrials, "dcv_kmeanspp_potentials: trials=%d (1..%d)", trials, kPpMaxTrials);
+    DCV_REQUIRE(ws_d && ws_bytes >= dcv_kmeanspp_workspace(n, trials), "dcv_kmeanspp_potentials: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int nb = km_blocks(n);
+    double* part = static_cast<double*>(ws_d);
+    DCV_PP_DISPATCH(kmeanspp_potentials_kernel, dim3(nb), dim3(kKmThreads), 0, s, P_d, n, offset_d, cand_d, (int)trials, closest_d, part)
+    DCV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kmeans_final_kernel, dim3((unsigned)trials), dim3(256), 0, s, part, nb, (int)trials, pot_d);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+extern "C" int dcv_kmeanspp_update(const double* P_d, int64_t n, int32_t d, const double* offset_d, const double* centre_d,
+                                   int32_t first, double* closest_d, double* pot_d, void* ws_d, size_t ws_bytes, void* stream) {
+    DCV_REQUIRE(P_d && centre_d && closest_d && pot_d && n > 0, "dcv_kmeanspp_update: bad arguments");
+    DCV_REQUIRE(ws_d && ws_bytes >= dcv_kmeanspp_workspace(n, 1), "dcv_kmeanspp_update: workspace too small");
+    hipStream_t s = as_stream(stream);
+    const int nb = km_blocks(n);
+    double* part = static_cast<double*>(ws_d);
+    DCV_PP_DISPATCH(kmeanspp_update_kernel, dim3(nb), dim3(kKmThreads), 0, s, P_d, n, offset_d, centre_d, (int)first, closest_d, part)
+    DCV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(kmeans_final_kernel, dim3(1), dim3(256), 0, s, part, nb, 1, pot_d);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }

@@ -742,9 +742,22 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
     __syncthreads();
     if (s_last) {
         __threadfence();
+        // partials of the other blocks come from memory (1-2 us each): G thread groups take the blocks b = g, g + G, ...
+        // with several loads in flight, then W threads add the G group sums in group order (fixed order: deterministic)
+        constexpr int G = 256 / W;
+        __shared__ double s_grp[G][W];
+        const int g = t / W, o = t - g * W;
+        if (g < G) {
+            double s = 0.0;
+#pragma unroll 4
+            for (unsigned b = g; b < gridDim.x; b += G) s += part[(int64_t)b * W + o];
+            s_grp[g][o] = s;
+        }
+        __syncthreads();
         if (t < W) {
             double s = 0.0;
-            for (unsigned b = 0; b < gridDim.x; ++b) s += part[(int64_t)b * W + t];
+#pragma unroll
+            for (int q = 0; q < G; ++q) s += s_grp[q][t];
             out[t] = s;
             red[0][t] = s;
         }

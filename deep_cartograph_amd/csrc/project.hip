@@ -173,17 +173,25 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(ProjArgs a) {
     }
 }
 
+// one workgroup per (min | max, component): threads take the blocks b = t, t + 256, ..., LDS tree (min / max are exact
+// in any order)
 template <int D>
-__global__ void project_minmax_final(const float* __restrict__ part, int nblocks, int d, float* __restrict__ minmax) {
+__global__ __launch_bounds__(256) void project_minmax_final(const float* __restrict__ part, int nblocks, int d, float* __restrict__ minmax) {
+    __shared__ float s_red[256];
     const int t = threadIdx.x;
-    if (t >= 2 * d) return;
-    const int which = t / d, c = t % d;
+    const int which = blockIdx.x / d, c = blockIdx.x % d;
     float v = which == 0 ? INFINITY : -INFINITY;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = t; b < nblocks; b += 256) {
         const float w = part[((int64_t)b * 2 + which) * D + c];
         v = which == 0 ? fminf(v, w) : fmaxf(v, w);
     }
-    minmax[which * d + c] = v;
+    s_red[t] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) s_red[t] = which == 0 ? fminf(s_red[t], s_red[t + o]) : fmaxf(s_red[t], s_red[t + o]);
+        __syncthreads();
+    }
+    if (t == 0) minmax[which * d + c] = s_red[0];
 }
 
 static int proj_blocks(int64_t n) {
@@ -215,7 +223,7 @@ static int launch_project(const ProjArgs& a, int nb, bool vec4, float* minmax, h
     }
     DCV_CHECK_LAUNCH();
     if (minmax) {
-        hipLaunchKernelGGL(project_minmax_final<D>, dim3(1), dim3(64), 0, s, a.part, nb, a.d, minmax);
+        hipLaunchKernelGGL(project_minmax_final<D>, dim3(2 * a.d), dim3(256), 0, s, a.part, nb, a.d, minmax);
         DCV_CHECK_LAUNCH();
     }
     return DCV_OK;

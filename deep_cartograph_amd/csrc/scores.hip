@@ -63,12 +63,20 @@ __global__ __launch_bounds__(kScThreads) void label_stats_kernel(const double* _
     for (int i = t; i < W; i += kScThreads) out[i] = ((s_acc[i] + s_acc[W + i]) + s_acc[2 * W + i]) + s_acc[3 * W + i];
 }
 
-__global__ void sum_blocks_kernel(const double* __restrict__ part, int nblocks, int width, double* __restrict__ acc) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= width) return;
+// acc[i] = sum over the blocks of part[b][i]: one workgroup per output, threads take b = t, t + 256, ... (independent
+// loads, all in flight), fixed LDS tree -- a single thread walking the partials pays one memory latency per partial.
+__global__ __launch_bounds__(256) void sum_blocks_kernel(const double* __restrict__ part, int nblocks, int width, double* __restrict__ acc) {
+    __shared__ double s_red[256];
+    const int i = blockIdx.x, t = threadIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[(int64_t)b * width + i];
-    acc[i] = s;
+    for (int b = t; b < nblocks; b += 256) s += part[(int64_t)b * width + i];
+    s_red[t] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (t < o) s_red[t] += s_red[t + o];
+        __syncthreads();
+    }
+    if (t == 0) acc[i] = s_red[0];
 }
 
 // S[i][c] = sum over the points j of cluster c of ||Q_i - P_j||.  P is sorted by cluster (cluster c
@@ -165,7 +173,7 @@ extern "C" int dcv_label_stats(const double* P_d, int64_t n, int32_t d, const in
     const size_t lds = ((size_t)k * d + 4 * (size_t)W) * sizeof(double);
     hipLaunchKernelGGL(label_stats_kernel, dim3(nb), dim3(kScThreads), lds, s, P_d, n, d, labels_d, centers_d, k, static_cast<double*>(ws_d));
     DCV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)cdiv(W, 256)), dim3(256), 0, s, static_cast<const double*>(ws_d), nb, W, acc_d);
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3((unsigned)W), dim3(256), 0, s, static_cast<const double*>(ws_d), nb, W, acc_d);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }
@@ -198,7 +206,7 @@ extern "C" int dcv_silhouette_sum(const double* S_d, int64_t nq, int32_t k, cons
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(silhouette_sum_kernel, dim3(nb), dim3(kScThreads), 0, s, S_d, nq, k, qlabels_d, start_d, static_cast<double*>(ws_d));
     DCV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(64), 0, s, static_cast<const double*>(ws_d), nb, 1, sum_d);
+    hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, s, static_cast<const double*>(ws_d), nb, 1, sum_d);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }

@@ -134,18 +134,40 @@ __global__ __launch_bounds__(kStatsThreads) void col_stats_kernel(const float* _
     }
 }
 
-__global__ void col_stats_final_kernel(const double* __restrict__ part, int nblocks, int F, double* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // index into [4][F]
-    if (i >= 4 * F) return;
-    const int stat = i / F;
+// out[stat][f] = combination over the blocks' partials, fixed order.  A block covers 64 consecutive outputs; its waves
+// take the partials b = wave, wave + 4, ... with eight loads in flight each (a single thread walking all 2048 partials
+// of an output one dependent load at a time took 855 us at F = 512 -- longer than the statistics pass itself) and are
+// combined in wave order.
+__global__ __launch_bounds__(256) void col_stats_final_kernel(const double* __restrict__ part, int nblocks, int F, double* __restrict__ out) {
+    __shared__ double s_red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + lane;  // index into [4][F]
+    const bool ok = i < 4 * F;
+    const int stat = ok ? i / F : 0;
     double acc = stat == 2 ? INFINITY : (stat == 3 ? -INFINITY : 0.0);
-    for (int b = 0; b < nblocks; ++b) {
-        const double v = part[(int64_t)b * 4 * F + i];
-        if (stat < 2) acc += v;
-        else if (stat == 2) acc = fmin(acc, v);
-        else acc = fmax(acc, v);
+    if (ok) {
+        const double* p = part + i;
+        const int64_t stride = (int64_t)4 * F;
+        if (stat < 2) {
+#pragma unroll 8
+            for (int b = wave; b < nblocks; b += 4) acc += p[(int64_t)b * stride];
+        } else if (stat == 2) {
+#pragma unroll 8
+            for (int b = wave; b < nblocks; b += 4) acc = fmin(acc, p[(int64_t)b * stride]);
+        } else {
+#pragma unroll 8
+            for (int b = wave; b < nblocks; b += 4) acc = fmax(acc, p[(int64_t)b * stride]);
+        }
     }
-    out[i] = acc;
+    s_red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        double r;
+        if (stat < 2) r = ((s_red[0][lane] + s_red[1][lane]) + s_red[2][lane]) + s_red[3][lane];
+        else if (stat == 2) r = fmin(fmin(s_red[0][lane], s_red[1][lane]), fmin(s_red[2][lane], s_red[3][lane]));
+        else r = fmax(fmax(s_red[0][lane], s_red[1][lane]), fmax(s_red[2][lane], s_red[3][lane]));
+        out[i] = r;
+    }
 }
 
 static int stats_blocks(int64_t n, int F) {
@@ -214,7 +236,7 @@ extern "C" int dcv_col_stats(const float* X_d, int64_t n, int32_t F, int64_t ld,
         hipLaunchKernelGGL(col_stats_kernel<1>, dim3(nb), dim3(kStatsThreads), lds, s, X_d, n, F, ld, part);
     }
     DCV_CHECK_LAUNCH();
-    hipLaunchKernelGGL(col_stats_final_kernel, dim3((4 * F + 255) / 256), dim3(256), 0, s, part, nb, F, out_d);
+    hipLaunchKernelGGL(col_stats_final_kernel, dim3((4 * F + 63) / 64), dim3(256), 0, s, part, nb, F, out_d);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }

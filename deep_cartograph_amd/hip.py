@@ -191,6 +191,33 @@ def kmeans_step(P: torch.Tensor, centers: torch.Tensor, labels: torch.Tensor, of
     return acc, md
 
 
+def kmeanspp_update(P: torch.Tensor, centre: torch.Tensor, closest: torch.Tensor, first: bool, offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """closest = first ? dist(., centre) : min(closest, dist(., centre)) in place; returns the new potential (1-element float64)."""
+    _require_gpu(P, centre, closest, offset)
+    _check_matrix(P, torch.float64)
+    lib = _lib.load()
+    n, d = P.shape
+    pot = torch.empty(1, dtype=torch.float64, device=P.device)
+    ws = _ws(lib.dcv_kmeanspp_workspace(n, 1), P.device)
+    check(lib.dcv_kmeanspp_update(_ptr(P), n, d, _ptr(offset), _ptr(centre), 1 if first else 0, _ptr(closest), _ptr(pot), _ptr(ws), ws.numel(),
+                                  _stream()), "dcv_kmeanspp_update")
+    return pot
+
+
+def kmeanspp_potentials(P: torch.Tensor, cand: torch.Tensor, closest: torch.Tensor, offset: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pot[t] = sum_i min(closest_i, dist(x_i, cand_t)) for the candidate centres cand (trials x d, offset frame)."""
+    _require_gpu(P, cand, closest, offset)
+    _check_matrix(P, torch.float64)
+    lib = _lib.load()
+    n, d = P.shape
+    t = cand.shape[0]
+    pot = torch.empty(t, dtype=torch.float64, device=P.device)
+    ws = _ws(lib.dcv_kmeanspp_workspace(n, t), P.device)
+    check(lib.dcv_kmeanspp_potentials(_ptr(P), n, d, _ptr(offset), _ptr(cand.contiguous()), t, _ptr(closest), _ptr(pot), _ptr(ws), ws.numel(),
+                                      _stream()), "dcv_kmeanspp_potentials")
+    return pot
+
+
 def label_stats(P: torch.Tensor, labels: torch.Tensor, k: int, centers: Optional[torch.Tensor] = None) -> torch.Tensor:
     """[sums (k*d) | counts (k) | sum ||x - c||^2 (k) | sum ||x - c|| (k)] per label, float64 on the device
     (the last two groups about `centers` when given)."""

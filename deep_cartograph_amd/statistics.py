@@ -63,41 +63,46 @@ class _DevicePoints:
 
 
 def _kmeans_plusplus(pts: _DevicePoints, k: int, rs: np.random.RandomState) -> np.ndarray:
-    """sklearn _kmeans_plusplus (unit weights) on the centred data.  The draws depend on a
-    sequential float64 cumsum + searchsorted, reproduced with the same NumPy calls on the host
-    copy of the closest-distance vector.  Over several ranks the centred shards are gathered in rank
-    (= frame) order and every rank runs the same seeded arithmetic on the whole set: identical
-    centres everywhere and identical to the single-process run (n x d float64 per rank, once per
-    initialisation: 0.64 GB for 20M x 4)."""
-    X = pts.comm.all_gather_rows(pts.P - pts.mean_t).cpu().numpy()
-    n = X.shape[0]
-    xsq = (X * X).sum(axis=1)
+    """sklearn _kmeans_plusplus (unit weights) on the centred data.  The distances to a new centre, the running minimum
+    and the candidates' potentials are HIP passes over the resident shard (dcv_kmeanspp_update / _potentials); the host
+    keeps what makes the draws reproducible: the RandomState stream and the sequential float64 cumsum + searchsorted
+    over the closest-distance vector (8 bytes per point leave the device per centre, not the points).  Over several
+    ranks that vector is gathered in rank (= frame) order, every rank runs the same seeded arithmetic and the candidate
+    rows are fetched from their owners: identical centres everywhere and identical to the single-process run."""
+    comm, dev, d = pts.comm, pts.dev, pts.d
+    n = pts.n
+    sizes = [int(v.item()) for v in comm.all_gather(torch.tensor([pts.n_local], dtype=torch.int64, device=dev))]
+    start = int(sum(sizes[: comm.rank]))
 
-    def sq_dists(C):
-        dmat = -2.0 * (C @ X.T)
-        dmat += (C * C).sum(axis=1)[:, None]
-        dmat += xsq[None, :]
-        np.maximum(dmat, 0, out=dmat)
-        return dmat
+    def rows(global_idx: np.ndarray) -> torch.Tensor:
+        """Centred coordinates of the points with the given global indices (every rank gets all of them)."""
+        gi = torch.as_tensor(np.asarray(global_idx, dtype=np.int64), device=dev)
+        mine = (gi >= start) & (gi < start + pts.n_local)
+        out = torch.zeros(len(gi), d, dtype=torch.float64, device=dev)
+        if bool(mine.any()):
+            out[mine] = pts.P[gi[mine] - start] - pts.mean_t
+        return comm.sum_(out)
 
-    centers = np.empty((k, X.shape[1]))
+    closest = torch.empty(pts.n_local, dtype=torch.float64, device=dev)
+    host = torch.empty(n, dtype=torch.float64, pin_memory=True)   # page-locked landing buffer of the distance vector
+    centers = np.empty((k, d))
     trials = 2 + int(np.log(k))
-    w = np.ones(n)
-    cid = rs.choice(n, p=w / w.sum())
-    centers[0] = X[cid]
-    closest = sq_dists(centers[0, None])
-    pot = closest @ w
+    # first centre: random_state.choice(n, p=uniform) -- one uniform draw against the cumulative weights
+    p_uniform = np.full(n, 1.0 / n)
+    cid = rs.choice(n, p=p_uniform)
+    c0 = rows([cid])
+    centers[0] = c0[0].cpu().numpy()
+    pot = float(comm.sum_(hip.kmeanspp_update(pts.P, c0[0].contiguous(), closest, True, offset=pts.mean_t)).item())
     for c in range(1, k):
         rand_vals = rs.uniform(size=trials) * pot
-        cand = np.searchsorted(np.cumsum(w * closest, dtype=np.float64).ravel(), rand_vals)
-        np.clip(cand, None, closest.size - 1, out=cand)
-        dc = sq_dists(X[cand])
-        np.minimum(closest, dc, out=dc)
-        cpot = dc @ w.reshape(-1, 1)
-        best = np.argmin(cpot)
-        pot = cpot[best]
-        closest = dc[best]
-        centers[c] = X[cand[best]]
+        host.copy_(comm.all_gather_rows(closest) if comm.active else closest)
+        cand = np.searchsorted(np.cumsum(host.numpy(), dtype=np.float64), rand_vals)   # sklearn stable_cumsum: sequential float64
+        np.clip(cand, None, n - 1, out=cand)
+        cand_rows = rows(cand)
+        pots = comm.sum_(hip.kmeanspp_potentials(pts.P, cand_rows, closest, offset=pts.mean_t)).cpu().numpy()
+        best = int(np.argmin(pots))
+        centers[c] = cand_rows[best].cpu().numpy()
+        pot = float(comm.sum_(hip.kmeanspp_update(pts.P, cand_rows[best].contiguous(), closest, False, offset=pts.mean_t)).item())
     return centers
 
 
@@ -162,6 +167,8 @@ def kmeans_clustering(feature_matrix: np.ndarray, num_clusters: int, n_init: int
         init = None
     if not (1 <= num_clusters <= 64) or pts.d > 16:
         raise NotImplementedError(f"the HIP k-means kernel supports k <= 64, d <= 16 (got k={num_clusters}, d={pts.d})")
+    if init is None and pts.d > 8:
+        raise NotImplementedError(f"the HIP k-means++ seeding passes support d <= 8 (got d={pts.d}); pass initial centroids")
     logger.debug(f"Number of clusters: {num_clusters}")
     best = None
     for _ in range(n_init):

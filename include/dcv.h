@@ -289,6 +289,20 @@ int dcv_kmeans_step(const double* P_d, int64_t n, int32_t d, const double* offse
                     const double* centers_d, int32_t k, int32_t* labels_d, double* acc_d, double* mindist_d /* n or NULL */,
                     void* ws_d, size_t ws_bytes, void* stream);
 
+/* k-means++ seeding passes.  Replace the distance / potential arithmetic of sklearn.cluster._kmeans._kmeans_plusplus as
+ * reached from statistics.kmeans_clustering, statistics.py:189 (init='k-means++'); the
+ * random draws and the sequential float64 cumsum + searchsorted that turn them into candidate rows stay with the caller.
+ * Points P (n x d float64, d <= 8), x_i = P_i - offset; dist(x, c) = max(-2 x.c + |c|^2 + |x|^2, 0).
+ *   dcv_kmeanspp_update      closest_i = first ? dist(x_i, centre) : min(closest_i, dist(x_i, centre));
+ *                            pot_d[0] = sum_i closest_i (adds over shards);
+ *   dcv_kmeanspp_potentials  pot_d[t] = sum_i min(closest_i, dist(x_i, cand_t)) for `trials` <= 8 candidate centres
+ *                            (trials x d, already in the offset frame). */
+size_t dcv_kmeanspp_workspace(int64_t n, int32_t trials);
+int dcv_kmeanspp_potentials(const double* P_d, int64_t n, int32_t d, const double* offset_d, const double* cand_d, int32_t trials,
+                            const double* closest_d, double* pot_d, void* ws_d, size_t ws_bytes, void* stream);
+int dcv_kmeanspp_update(const double* P_d, int64_t n, int32_t d, const double* offset_d, const double* centre_d, int32_t first,
+                        double* closest_d, double* pot_d, void* ws_d, size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------- k-selection scores
  * Replace sklearn.metrics calinski_harabasz_score / davies_bouldin_score / silhouette_score as called
  * by statistics.optimize_clustering, statistics.py:73-75, on points P (n x d float64, d <= 16) and

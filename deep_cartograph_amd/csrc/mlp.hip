@@ -85,7 +85,8 @@ struct dcv_mlp {
 
 namespace dcv {
 
-constexpr int kColsumRows = 128;
+constexpr int kColsumRows = 32;    // rows per block of colsum_kernel (a block walks its rows serially: short blocks, many of them)
+constexpr int kSseRows = 16;       // rows per block of ae_sse_kernel
 constexpr int kStatBlockRows = 128;
 
 // ------------------------------------------------------------------ small kernels
@@ -994,8 +995,8 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
                                                      const float* __restrict__ range, double* __restrict__ part) {
     __shared__ double red[256];
     const int t = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    const int64_t r1 = r0 + 64 < R ? r0 + 64 : R;
+    const int64_t r0 = (int64_t)blockIdx.x * kSseRows;
+    const int64_t r1 = r0 + kSseRows < R ? r0 + kSseRows : R;
     double s = 0.0;
     for (int64_t r = r0; r < r1; ++r) {
         const float* y = Y + r * ldy;
@@ -1272,7 +1273,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     const int d = m->d_out;
     m->stats_len = desc->model == DCV_MODEL_DEEPTICA ? 2 * d + 2 * d * d : 1;
     m->log_width = desc->model == DCV_MODEL_DEEPTICA ? 2 + 2 * d * d + d : 2;
-    m->spart_blocks = desc->model == DCV_MODEL_DEEPTICA ? (int)cdiv(desc->max_batch, kStatBlockRows) : (int)cdiv(m->rows_cap, 64);
+    m->spart_blocks = desc->model == DCV_MODEL_DEEPTICA ? (int)cdiv(desc->max_batch, kStatBlockRows) : (int)cdiv(m->rows_cap, kSseRows);
     const int dl = desc->model == DCV_MODEL_AE ? desc->dims[desc->latent_layer] : d;
     if (rc == DCV_OK) rc = dmalloc(&m->params, (size_t)m->n_params);
     if (rc == DCV_OK) rc = dmalloc(&m->grads, (size_t)m->n_params);
@@ -1584,7 +1585,7 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
         hipLaunchKernelGGL(sum_partials_kernel, dim3(m->stats_len), dim3(64), 0, s, m->spart, nb, m->stats_len, m->stats);
         DCV_CHECK_LAUNCH();
     } else {
-        const int nb = (int)cdiv(R, 64);
+        const int nb = (int)cdiv(R, kSseRows);
         hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart);
         DCV_CHECK_LAUNCH();
         hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, m->spart, nb, 1, m->stats);

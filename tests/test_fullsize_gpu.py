@@ -187,3 +187,113 @@ def test_c5_kmeans_pass_properties():
     dist, rows = hip.nearest_rows(P, newC)
     assert bool(torch.all((rows >= 0) & (rows < n)))
     np.testing.assert_allclose(dist.cpu().numpy(), torch.linalg.norm(P[rows] - newC, dim=1).cpu().numpy(), rtol=1e-12, atol=1e-15)
+
+
+def test_c5_deeptica_leg_properties():
+    """C5 at full single-GPU size: 20M x 1024 float32 (82 GB resident), Deep-TICA 1024-256-128-4, lag 10.  The statistics
+    and in-place standardisation of the whole matrix, training steps at F = 1024 (the loss of a held-out batch improves; the
+    batch statistics of two half batches add up to the full batch's; row sharing equals the two-half evaluation), the
+    projection of all 20M frames (chunking independence, extrema consistent with the output), then the '%.4f' seam and
+    k-means with k-means++ seeding on the 20M x 4 projection (every point labelled once, seeding passes on the device)."""
+    from deep_cartograph_amd import hip, statistics
+    from deep_cartograph_amd.synth import synth_features
+
+    n, F, lag, B = 20_000_000, 1024, 10, 65_526
+    X = synth_features(n, F, k_slow=4, device="cuda")
+    raw = hip.col_stats_raw(X)
+    st = hip.finalize_stats(raw, n)
+    hip.normalize(X, torch.from_numpy(st["mean"]).cuda(), torch.from_numpy(st["std"]).cuda(), out=X)
+    stn = hip.finalize_stats(hip.col_stats_raw(X[:5_000_000]), 5_000_000)
+    assert np.max(np.abs(stn["std"] - 1.0)) < 0.05 and np.max(np.abs(stn["mean"])) < 0.3    # a 5M block of a standardised AR(1) matrix
+    dims, acts = [F, 256, 128, 4], ["leaky_relu", "leaky_relu", None]
+    torch.manual_seed(43)
+    lins = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(3)]
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=B, lag=lag, tica_reg=1e-6, lr=1e-3)
+    eng.set_linears([(l.weight.detach().numpy().copy(), l.bias.detach().numpy().copy()) for l in lins])
+    eng.reset_log(256)
+    sv = eng.stats_view()
+    eng.forward(X, row0=0, batch=B)
+    full = sv.clone()
+    h = B // 2
+    eng.forward(X, row0=0, batch=h)
+    s1 = sv.clone()
+    eng.forward(X, row0=h, batch=h)
+    np.testing.assert_allclose((s1 + sv).cpu().numpy(), full.cpu().numpy(), rtol=1e-9, atol=1e-6)
+    eng.set_row_sharing(False)
+    eng.forward(X, row0=0, batch=B)
+    np.testing.assert_allclose(sv.cpu().numpy(), full.cpu().numpy(), rtol=1e-6, atol=1e-3)
+    eng.set_row_sharing(True)
+    held = 19_000_000
+    eng.reset_log(256)
+    eng.eval_step(X, row0=held, batch=B)
+    for i in range(60):
+        eng.train_step(X, row0=(i * B) % 16_000_000, batch=B)
+    eng.eval_step(X, row0=held, batch=B)
+    rec = eng.read_log()
+    assert np.all(np.isfinite(rec[:, 0])) and rec[-1, 0] < rec[0, 0] - 0.05 and rec[-1, 0] >= -4.0   # -sum(eig^2) in [-d, 0]
+    # projection of every frame: chunk independence and extrema
+    out, mm = eng.infer(X, want_minmax=True)
+    assert out.shape == (n, 4) and bool(torch.isfinite(out).all())
+    assert torch.equal(mm[0], out.min(dim=0).values) and torch.equal(mm[1], out.max(dim=0).values)
+    part, _ = eng.infer(X[7_777_777:8_123_456])
+    assert torch.equal(part, out[7_777_777:8_123_456])
+    eng.close()
+    del X
+    torch.cuda.empty_cache()
+    # '%.4f' seam + k-means with k-means++ seeding on the 20M x 4 projection scaled to [-1, 1]
+    cvs = ((out - (mm[1] + mm[0]) / 2) / ((mm[1] - mm[0]) / 2)).cpu().numpy().astype(np.float64)
+    P = np.round(cvs, 4)
+    labels, centers = statistics.kmeans_clustering(P, 6, 1)
+    assert labels.shape == (n,) and set(np.unique(labels)) == set(range(6))
+    assert centers.shape == (6, 4) and np.all(np.abs(centers) <= 1.0)
+    # the centres are the member means of the last M-step; sklearn stops on the centre shift (tol) and re-labels once against
+    # them, so they sit within the tolerance of the final members' means, and every point is nearest to its own centre
+    for j in range(6):
+        np.testing.assert_allclose(P[labels == j].mean(axis=0), centers[j], atol=5e-3)
+    sub = P[::997]
+    d2 = ((sub[:, None, :] - centers[None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(np.argmin(d2, axis=1), labels[::997])
+
+
+def test_c2_autoencoder_properties():
+    """C2 at full size: 1M x 128, autoencoder 128-64-32-2-32-64-128, batch 4096.  The squared-error statistic of two half
+    batches adds up to the full batch's, the reconstruction loss of a held-out batch falls over one epoch of training
+    steps, an evaluation step leaves the parameters untouched, and the latent projection does not depend on chunking."""
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd.synth import synth_features
+
+    n, F, B = 1_000_000, 128, 4096
+    X = synth_features(n, F, k_slow=2, device="cuda")
+    st = hip.finalize_stats(hip.col_stats_raw(X), n)
+    Xn = hip.normalize(X, torch.from_numpy(st["mean"]).cuda(), torch.from_numpy(st["std"]).cuda())
+    dims = [F, 64, 32, 2, 32, 64, F]
+    acts = ["leaky_relu", "leaky_relu", None, "leaky_relu", "leaky_relu", None]
+    torch.manual_seed(43)
+    lins = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(6)]
+    eng = hip.Mlp("ae", dims, acts, max_batch=B, latent_layer=3, lr=1e-3)
+    eng.set_linears([(l.weight.detach().numpy().copy(), l.bias.detach().numpy().copy()) for l in lins])
+    eng.set_feature_range(st["std"])
+    eng.reset_log(512)
+    sv = eng.stats_view()
+    eng.forward(Xn, row0=0, batch=B)
+    full = sv.clone()
+    eng.forward(Xn, row0=0, batch=B // 2)
+    s1 = sv.clone()
+    eng.forward(Xn, row0=B // 2, batch=B // 2)
+    np.testing.assert_allclose((s1 + sv).cpu().numpy(), full.cpu().numpy(), rtol=1e-10)
+    held = 900_000
+    before = eng.get_linears()
+    eng.eval_step(Xn, row0=held, batch=B)
+    after = eng.get_linears()
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(before, after))
+    for i in range(195):   # one epoch of the 0.8 training share
+        eng.train_step(Xn, row0=i * B, batch=B)
+    eng.eval_step(Xn, row0=held, batch=B)
+    rec = eng.read_log()
+    assert np.all(np.isfinite(rec[:, 0])) and rec[-1, 0] < 0.8 * rec[0, 0]
+    whole, mm = eng.infer(Xn, want_minmax=True)
+    assert whole.shape == (n, 2)
+    part, _ = eng.infer(Xn[123_457:345_679])
+    assert torch.equal(part, whole[123_457:345_679])
+    assert torch.equal(mm[0], whole.min(dim=0).values) and torch.equal(mm[1], whole.max(dim=0).values)
+    eng.close()

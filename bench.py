@@ -118,12 +118,8 @@ class Fit:
         eng, r0 = self.eng, (i % self.steps_per_epoch) * self.lb
         if self.dist is None:
             eng.train_step(self.Xn, row0=r0, batch=self.lb)
-        else:
-            eng.forward(self.Xn, row0=r0, batch=self.lb)
-            self.dist.all_reduce(self.sv, op=self.dist.ReduceOp.SUM)
-            eng.backward(self.Xn, row0=r0, batch=self.lb, global_batch=self.gb, train=True)
-            self.dist.all_reduce(self.gv, op=self.dist.ReduceOp.SUM)
-            eng.apply()
+        else:   # statistics all-reduce, then the gradient all-reduce of the upper layers under the layer-0 weight gradient
+            eng.data_parallel_step(self.Xn, self.dist, self.gb, row0=r0, batch=self.lb, train=True)
 
     def validation_pass(self):
         eng = self.eng
@@ -132,9 +128,7 @@ class Fit:
             if self.dist is None:
                 eng.eval_step(self.Xn, row0=r0, batch=self.lb)
             else:
-                eng.forward(self.Xn, row0=r0, batch=self.lb, train=False)
-                self.dist.all_reduce(self.sv, op=self.dist.ReduceOp.SUM)
-                eng.backward(self.Xn, row0=r0, batch=self.lb, global_batch=self.gb, train=False)
+                eng.data_parallel_step(self.Xn, self.dist, self.gb, row0=r0, batch=self.lb, train=False)
 
     def barrier(self):
         if self.dist is not None:

@@ -49,6 +49,8 @@ struct dcv_mlp {
     double momentum_rt;        // beta1 (Adam family) or momentum (SGD, RMSprop): dcv_mlp_set_momentum
     bool any_drop;             // some layer has dropout p > 0
     bool fwd_train;            // the last forward ran in training mode (dropout active): backward must agree
+    void (*upper_cb)(void*);   // data-parallel overlap hook (dcv_mlp_set_upper_grads_callback) or null
+    void* upper_cb_user;
     bool head_done;            // the last forward already ran the d x d loss head inside its statistics launch (one-GPU steps)
     int64_t drop_step;         // training forwards so far = step field of the next forward's dropout counters
     int64_t cur_step;          // step field of the last training forward
@@ -1228,6 +1230,8 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     for (int l = 0; l < L; ++l) m->any_drop = m->any_drop || desc->dropout[l] > 0.f;
     m->fwd_train = false;
     m->head_done = false;
+    m->upper_cb = nullptr;
+    m->upper_cb_user = nullptr;
     m->drop_step = 0;
     m->cur_step = 0;
     m->prof_level = m->prof_cap = m->prof_step = 0;
@@ -1370,6 +1374,13 @@ extern "C" int dcv_mlp_set_lr(dcv_mlp* m, double lr) {
 extern "C" int dcv_mlp_set_momentum(dcv_mlp* m, double value) {
     DCV_REQUIRE(m, "dcv_mlp_set_momentum: null");
     m->momentum_rt = value;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void*), void* user) {
+    DCV_REQUIRE(m, "dcv_mlp_set_upper_grads_callback: null");
+    m->upper_cb = fn;
+    m->upper_cb_user = user;
     return DCV_OK;
 }
 
@@ -1595,6 +1606,33 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
     return DCV_OK;
 }
 
+// Gradient reduction of the layers [l0, l1) of `ra` (split-K slabs + bias partials -> m->grads), optionally with the
+// optimiser update fused in.
+static int launch_reduce(dcv_mlp* m, const ReduceArgs& ra_all, int l0, int l1, bool fuse_opt, const OptArgs& oa, hipStream_t s) {
+    ReduceArgs ra;
+    ra.L = l1 - l0;
+    int max_splits = 0, max_bblocks = 0;
+    int64_t max_total = 0;
+    for (int l = l0; l < l1; ++l) {
+        ra.l[l - l0] = ra_all.l[l];
+        if (ra_all.l[l].splits > max_splits) max_splits = ra_all.l[l].splits;
+        if (ra_all.l[l].bblocks > max_bblocks) max_bblocks = ra_all.l[l].bblocks;
+        if (ra_all.l[l].w_count + ra_all.l[l].out > max_total) max_total = ra_all.l[l].w_count + ra_all.l[l].out;
+    }
+    if (ra.L <= 0) return DCV_OK;
+    if (max_splits <= 512 && max_bblocks <= 1024) {   // few partials per weight (the few bias elements may see more)
+        int64_t bx = cdiv(max_total, 64);
+        if (bx > 2048) bx = 2048;
+        hipLaunchKernelGGL(reduce_grads_small_kernel, dim3((unsigned)bx, ra.L), dim3(256), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params,
+                           m->adam_m, m->adam_v, m->opt_aux, oa);
+    } else {
+        hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, ra.L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params, m->adam_m,
+                           m->adam_v, m->opt_aux, oa);
+    }
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
 static OptArgs next_opt_args(dcv_mlp* m);
 static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                          int64_t global_batch, int32_t train, void* stream, bool fuse_opt = false) {
@@ -1653,8 +1691,18 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, last.out, m->ld_dz, m->layers[L - 1].bpart);
         DCV_CHECK_LAUNCH();
     }
+    bool upper_done = false;
     for (int l = L - 1; l >= 0; --l) {
         LayerPlan& p = m->layers[l];
+        if (l == 0 && L > 1 && m->upper_cb && !fuse_opt) {
+            // Data-parallel overlap: everything the gradients of layers 1 .. L-1 need has been enqueued (their slabs, and
+            // the bias partials of every layer).  Reduce them now and tell the caller, who starts their all-reduce on a
+            // side stream while the largest product of the step -- the layer-0 weight gradient -- still runs here.
+            int rcu = launch_reduce(m, ra, 1, L, false, OptArgs{}, s);
+            if (rcu) return rcu;
+            upper_done = true;
+            m->upper_cb(m->upper_cb_user);
+        }
         // wgrad: dW = dZ^T In  (M = out, N = in, K = rows)
         int64_t kc, splits;
         wgrad_plan(p.out, p.in, R, &kc, &splits);
@@ -1731,23 +1779,8 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     }
     OptArgs oa{};
     if (fuse_opt) oa = next_opt_args(m);
-    int max_splits = 0, max_bblocks = 0;
-    int64_t max_total = 0;
-    for (int l = 0; l < L; ++l) {
-        if (ra.l[l].splits > max_splits) max_splits = ra.l[l].splits;
-        if (ra.l[l].bblocks > max_bblocks) max_bblocks = ra.l[l].bblocks;
-        if (ra.l[l].w_count + ra.l[l].out > max_total) max_total = ra.l[l].w_count + ra.l[l].out;
-    }
-    if (max_splits <= 512 && max_bblocks <= 1024) {   // few partials per weight (the few bias elements may see more)
-        int64_t bx = cdiv(max_total, 64);
-        if (bx > 2048) bx = 2048;
-        hipLaunchKernelGGL(reduce_grads_small_kernel, dim3((unsigned)bx, L), dim3(256), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params,
-                           m->adam_m, m->adam_v, m->opt_aux, oa);
-    } else {
-        hipLaunchKernelGGL(reduce_grads_kernel, dim3(512, L), dim3(64 * kRedWaves), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params, m->adam_m,
-                           m->adam_v, m->opt_aux, oa);
-    }
-    DCV_CHECK_LAUNCH();
+    int rc2 = launch_reduce(m, ra, 0, upper_done ? 1 : L, fuse_opt, oa, s);   // layer 0 only when the upper layers went out early
+    if (rc2) return rc2;
     if (m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
     return DCV_OK;
 }

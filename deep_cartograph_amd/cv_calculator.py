@@ -877,12 +877,7 @@ class NonLinear(CVCalculator):
         if not self.comm.active:
             (self.engine.train_step if train else self.engine.eval_step)(Xn, **kw)
             return
-        self.engine.forward(Xn, train=train, **kw)
-        self.comm.sum_(self._stats_view)
-        self.engine.backward(Xn, global_batch=global_batch_of(n), train=train, **kw)
-        if train:
-            self.comm.sum_(self._grads_view)
-            self.engine.apply()
+        self.engine.data_parallel_step(Xn, self.comm._dist, global_batch_of(n), train=train, group=self.comm.group, **kw)
 
     def _records_to_metrics(self, rec: np.ndarray):
         """(weighted mean loss, weighted mean eigenvalues or None, TICA buffers of the last record)."""

@@ -440,10 +440,48 @@ class Mlp:
         batch = int(batch if batch is not None else idx.numel())
         check(self.lib.dcv_mlp_forward(self.h, *self._args(Xn, idx, row0, batch), 1 if train else 0, _stream()), "dcv_mlp_forward")
 
-    def backward(self, Xn, idx=None, row0=0, batch=None, global_batch=None, train=True):
+    def backward(self, Xn, idx=None, row0=0, batch=None, global_batch=None, train=True, on_upper_grads=None):
+        """`on_upper_grads`: host callable invoked inside the call once the gradients of layers 1.. are reduced into
+        upper_grads_view() and before the layer-0 weight gradient is enqueued (data-parallel overlap hook)."""
+        import ctypes as C
+
         batch = int(batch if batch is not None else idx.numel())
         gb = int(global_batch if global_batch is not None else batch)
-        check(self.lib.dcv_mlp_backward(self.h, *self._args(Xn, idx, row0, batch), gb, 1 if train else 0, _stream()), "dcv_mlp_backward")
+        cb = None
+        if on_upper_grads is not None and train and self.L > 1:
+            cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _u: on_upper_grads())
+            check(self.lib.dcv_mlp_set_upper_grads_callback(self.h, C.cast(cb, C.c_void_p), None), "dcv_mlp_set_upper_grads_callback")
+        try:
+            check(self.lib.dcv_mlp_backward(self.h, *self._args(Xn, idx, row0, batch), gb, 1 if train else 0, _stream()), "dcv_mlp_backward")
+        finally:
+            if cb is not None:
+                check(self.lib.dcv_mlp_set_upper_grads_callback(self.h, None, None), "dcv_mlp_set_upper_grads_callback")
+
+    def upper_grads_view(self) -> torch.Tensor:
+        """Gradients of layers 1.. (the tail of the flat buffer)."""
+        return self.grads_view()[self.offsets[1][0]:] if self.L > 1 else self.grads_view()[:0]
+
+    def layer0_grads_view(self) -> torch.Tensor:
+        return self.grads_view()[: self.offsets[1][0]] if self.L > 1 else self.grads_view()
+
+    def data_parallel_step(self, Xn, dist, global_batch, idx=None, row0=0, batch=None, train=True, group=None):
+        """One synchronous data-parallel step over `dist` (torch.distributed): forward, all-reduce of the batch
+        statistics, backward with the gradient all-reduce of the upper layers started under the layer-0 weight
+        gradient, all-reduce of the layer-0 part, optimiser update."""
+        self.forward(Xn, idx=idx, row0=row0, batch=batch, train=train)
+        dist.all_reduce(self.stats_view(), op=dist.ReduceOp.SUM, group=group)
+        if not train:
+            self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=False)
+            return
+        pending = []
+        upper, lower = self.upper_grads_view(), self.layer0_grads_view()
+        self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=True,
+                      on_upper_grads=(lambda: pending.append(dist.all_reduce(upper, op=dist.ReduceOp.SUM, group=group, async_op=True)))
+                      if upper.numel() else None)
+        dist.all_reduce(lower, op=dist.ReduceOp.SUM, group=group)
+        for w in pending:
+            w.wait()
+        self.apply()
 
     def apply(self):
         check(self.lib.dcv_mlp_apply(self.h, _stream()), "dcv_mlp_apply")

@@ -213,6 +213,13 @@ int32_t dcv_mlp_stats_len(const dcv_mlp* m);
 int dcv_mlp_backward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
                      int32_t batch, int64_t global_batch, int32_t train, void* stream);
 int dcv_mlp_apply(dcv_mlp* m, void* stream);
+/* Data-parallel overlap hook.  With a callback set, dcv_mlp_backward(train = 1) reduces the gradients of layers
+ * 1 .. n_layers-1 into dcv_mlp_grads() BEFORE it enqueues the layer-0 weight gradient (the largest product of the
+ * step) and calls fn(user) on the host at that point: the caller starts the all-reduce of that part of the buffer --
+ * floats [dcv_mlp_param_offset(m, 1, 0), dcv_mlp_num_params) -- on a side stream ordered after the launch stream, so
+ * the exchange runs under the layer-0 product; the layer-0 part [0, dcv_mlp_param_offset(m, 1, 0)) is reduced when
+ * the call returns.  fn = NULL restores the single reduction. */
+int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void* user), void* user);
 /* Convenience for one GPU: forward + backward(train=1) + apply. */
 int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
                        int32_t batch, void* stream);

@@ -348,11 +348,14 @@ def _dp_rank(rank, world, port, tmpdir):
     sv, gv = eng.stats_view(), eng.grads_view()
     for i in range(steps):
         r0 = i * lb
-        eng.forward(Xd, row0=r0, batch=lb)
-        dist.all_reduce(sv, op=dist.ReduceOp.SUM)
-        eng.backward(Xd, row0=r0, batch=lb, global_batch=lb * world, train=True)
-        dist.all_reduce(gv, op=dist.ReduceOp.SUM)
-        eng.apply()
+        if i % 2 == 0:   # the engine's own sequence: upper-layer gradients all-reduced under the layer-0 weight gradient
+            eng.data_parallel_step(Xd, dist, lb * world, row0=r0, batch=lb)
+        else:            # the same step written out with one gradient all-reduce
+            eng.forward(Xd, row0=r0, batch=lb)
+            dist.all_reduce(sv, op=dist.ReduceOp.SUM)
+            eng.backward(Xd, row0=r0, batch=lb, global_batch=lb * world, train=True)
+            dist.all_reduce(gv, op=dist.ReduceOp.SUM)
+            eng.apply()
     torch.cuda.synchronize()
     lin = eng.get_linears()
     np.savez(os.path.join(tmpdir, f"dp_rank{rank}.npz"), loss=eng.read_log()[:steps, 0], **{f"w{i}": w for i, (w, _) in enumerate(lin)})

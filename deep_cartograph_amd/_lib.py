@@ -110,6 +110,8 @@ SIGNATURES = {
     "dcv_cluster_dist_sums": (C.c_int, [_P, _I64, _P, _P, _I32, _I32, _P, _P]),
     "dcv_silhouette_sum_workspace": (_SZ, [_I64]),
     "dcv_silhouette_sum": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _SZ, _P]),
+    "dcv_linear_binning_workspace": (_SZ, [_I32, _I32]),
+    "dcv_linear_binning": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P, _I32, _P, _P, _P, _SZ, _P]),
     "dcv_nearest_rows_workspace": (_SZ, [_I64, _I32, _I32]),
     "dcv_nearest_rows": (C.c_int, [_P, _I64, _I32, _P, _I32, _I64, _P, _P, _P, _SZ, _P]),
     "dcv_nearest_point": (C.c_int, [_P, _I64, _P, _I64, _I32, _P, _P]),

@@ -153,6 +153,67 @@ __global__ __launch_bounds__(kScThreads) void silhouette_sum_kernel(const double
     }
 }
 
+// ------------------------------------------------------------------ linear binning (first stage of the binned KDE behind the FES)
+// Every point spreads unit weight over the 2^d grid nodes around it, proportionally to proximity (KDEpy's linear binning).
+// Weights are accumulated as 64-bit fixed point (2^-36 resolution): integer atomics commute, so the grid is the same
+// whatever the order of the threads.  1-D grids that fit LDS are built per block first.
+constexpr double kBinScale = 68719476736.0;   // 2^36
+template <int D>
+__global__ __launch_bounds__(kScThreads) void linear_binning_kernel(const double* __restrict__ P, int64_t n, int64_t ldp, int c0, int c1,
+                                                                    double lo0, double inv0, double lo1, double inv1, int bins,
+                                                                    unsigned long long* __restrict__ grid, unsigned long long* __restrict__ outside) {
+    extern __shared__ unsigned long long s_grid[];
+    const bool local = D == 1 && bins <= 4096;
+    if (local) {
+        for (int i = threadIdx.x; i < bins; i += kScThreads) s_grid[i] = 0ull;
+        __syncthreads();
+    }
+    unsigned long long miss = 0ull;
+    for (int64_t i = (int64_t)blockIdx.x * kScThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kScThreads) {
+        const double t0 = (P[i * ldp + c0] - lo0) * inv0;   // position in grid-spacing units
+        if (!(t0 >= 0.0 && t0 <= (double)(bins - 1))) { ++miss; continue; }
+        int i0 = (int)t0;
+        if (i0 > bins - 2) i0 = bins - 2;
+        const double f0 = t0 - (double)i0;
+        if constexpr (D == 1) {
+            const unsigned long long w1 = (unsigned long long)(f0 * kBinScale + 0.5), w0 = (unsigned long long)kBinScale - w1;
+            if (local) {
+                atomicAdd(&s_grid[i0], w0);
+                atomicAdd(&s_grid[i0 + 1], w1);
+            } else {
+                atomicAdd(&grid[i0], w0);
+                atomicAdd(&grid[i0 + 1], w1);
+            }
+        } else {
+            const double t1 = (P[i * ldp + c1] - lo1) * inv1;
+            if (!(t1 >= 0.0 && t1 <= (double)(bins - 1))) { ++miss; continue; }
+            int j0 = (int)t1;
+            if (j0 > bins - 2) j0 = bins - 2;
+            const double f1 = t1 - (double)j0;
+            const unsigned long long w11 = (unsigned long long)(f0 * f1 * kBinScale + 0.5);
+            const unsigned long long w10 = (unsigned long long)(f0 * (1.0 - f1) * kBinScale + 0.5);
+            const unsigned long long w01 = (unsigned long long)((1.0 - f0) * f1 * kBinScale + 0.5);
+            const unsigned long long w00 = (unsigned long long)kBinScale - w11 - w10 - w01;
+            unsigned long long* g = grid + (int64_t)i0 * bins + j0;   // grid[i][j]: first coordinate = row
+            atomicAdd(g, w00);
+            atomicAdd(g + 1, w01);
+            atomicAdd(g + bins, w10);
+            atomicAdd(g + bins + 1, w11);
+        }
+    }
+    if (miss) atomicAdd(outside, miss);
+    if (local) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < bins; i += kScThreads)
+            if (s_grid[i]) atomicAdd(&grid[i], s_grid[i]);
+    }
+}
+
+__global__ void binning_to_double_kernel(const unsigned long long* __restrict__ fixed, int64_t cells, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cells) out[i] = (double)fixed[i] / kBinScale;
+}
+
 }  // namespace dcv
 
 using namespace dcv;
@@ -208,5 +269,47 @@ extern "C" int dcv_silhouette_sum(const double* S_d, int64_t nq, int32_t k, cons
     DCV_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_blocks_kernel, dim3(1), dim3(256), 0, s, static_cast<const double*>(ws_d), nb, 1, sum_d);
     DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+extern "C" size_t dcv_linear_binning_workspace(int32_t d, int32_t bins) {
+    if (d < 1 || d > 2 || bins < 2) return 0;
+    const size_t cells = d == 1 ? (size_t)bins : (size_t)bins * bins;
+    return (cells + 1) * sizeof(unsigned long long);
+}
+
+extern "C" int dcv_linear_binning(const double* P_d, int64_t n, int64_t ldp, int32_t d, const int32_t* cols_h, const double* lo_h,
+                                  const double* hi_h, int32_t bins, double* grid_d, int64_t* outside_h, void* ws_d, size_t ws_bytes,
+                                  void* stream) {
+    DCV_REQUIRE(P_d && cols_h && lo_h && hi_h && grid_d && n > 0, "dcv_linear_binning: bad arguments");
+    DCV_REQUIRE((d == 1 || d == 2) && bins >= 2 && bins <= 8192, "dcv_linear_binning: d=%d (1 or 2) bins=%d (2..8192) unsupported", d, bins);
+    DCV_REQUIRE(ws_d && ws_bytes >= dcv_linear_binning_workspace(d, bins), "dcv_linear_binning: workspace too small");
+    for (int c = 0; c < d; ++c) DCV_REQUIRE(hi_h[c] > lo_h[c] && cols_h[c] >= 0 && cols_h[c] < ldp, "dcv_linear_binning: bad bounds / column");
+    hipStream_t s = as_stream(stream);
+    const int64_t cells = d == 1 ? bins : (int64_t)bins * bins;
+    unsigned long long* fixed = static_cast<unsigned long long*>(ws_d);
+    DCV_CHECK_HIP(hipMemsetAsync(fixed, 0, (cells + 1) * sizeof(unsigned long long), s));
+    int64_t nb = cdiv(n, (int64_t)kScThreads * 8);
+    if (nb > (int64_t)num_cus() * 8) nb = (int64_t)num_cus() * 8;
+    if (nb < 1) nb = 1;
+    const double inv0 = (double)(bins - 1) / (hi_h[0] - lo_h[0]);
+    if (d == 1) {
+        const size_t lds = bins <= 4096 ? (size_t)bins * sizeof(unsigned long long) : 0;
+        hipLaunchKernelGGL(linear_binning_kernel<1>, dim3((unsigned)nb), dim3(kScThreads), lds, s, P_d, n, ldp, (int)cols_h[0], 0, lo_h[0], inv0, 0.0,
+                           0.0, (int)bins, fixed, fixed + cells);
+    } else {
+        const double inv1 = (double)(bins - 1) / (hi_h[1] - lo_h[1]);
+        hipLaunchKernelGGL(linear_binning_kernel<2>, dim3((unsigned)nb), dim3(kScThreads), 0, s, P_d, n, ldp, (int)cols_h[0], (int)cols_h[1], lo_h[0],
+                           inv0, lo_h[1], inv1, (int)bins, fixed, fixed + cells);
+    }
+    DCV_CHECK_LAUNCH();
+    hipLaunchKernelGGL(binning_to_double_kernel, dim3((unsigned)cdiv(cells, 256)), dim3(256), 0, s, fixed, cells, grid_d);
+    DCV_CHECK_LAUNCH();
+    if (outside_h) {
+        unsigned long long miss = 0;
+        DCV_CHECK_HIP(hipMemcpyAsync(&miss, fixed + cells, sizeof(miss), hipMemcpyDeviceToHost, s));
+        DCV_CHECK_HIP(hipStreamSynchronize(s));
+        *outside_h = (int64_t)miss;
+    }
     return DCV_OK;
 }

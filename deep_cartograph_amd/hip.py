@@ -255,6 +255,26 @@ def silhouette_sum(S: torch.Tensor, qlabels: torch.Tensor, start: torch.Tensor) 
     return out
 
 
+def linear_binning(P: torch.Tensor, cols, lo, hi, bins: int):
+    """Linear-binning weights of the points on a bins^d grid over [lo, hi] (d = len(cols) <= 2): (grid float64 device
+    tensor of shape (bins,) or (bins, bins), number of points outside the bounds)."""
+    import ctypes as C
+
+    _require_gpu(P)
+    _check_matrix(P, torch.float64)
+    lib = _lib.load()
+    d = len(cols)
+    cols_a = (C.c_int32 * d)(*[int(c) for c in cols])
+    lo_a = (C.c_double * d)(*[float(v) for v in lo])
+    hi_a = (C.c_double * d)(*[float(v) for v in hi])
+    grid = torch.empty((bins,) * d, dtype=torch.float64, device=P.device)
+    ws = _ws(lib.dcv_linear_binning_workspace(d, bins), P.device)
+    out = C.c_int64(0)
+    check(lib.dcv_linear_binning(_ptr(P), P.shape[0], P.stride(0), d, cols_a, lo_a, hi_a, int(bins), _ptr(grid), C.byref(out), _ptr(ws),
+                                 ws.numel(), _stream()), "dcv_linear_binning")
+    return grid, int(out.value)
+
+
 def nearest_rows(P: torch.Tensor, centers: torch.Tensor, row_offset: int = 0):
     """Per centroid: (distance, global row) of the nearest point (np.linalg.norm, first index on ties)."""
     _require_gpu(P, centers)

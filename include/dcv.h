@@ -332,6 +332,18 @@ size_t dcv_silhouette_sum_workspace(int64_t nq);
 int dcv_silhouette_sum(const double* S_d, int64_t nq, int32_t k, const int32_t* qlabels_d, const int64_t* start_d,
                        double* sum_d, void* ws_d, size_t ws_bytes, void* stream);
 
+/* Free-energy surface of the projected trajectory (second half).  The reference plots
+ * mlcolvar.utils.fes.compute_fes(data, backend="KDEpy", num_samples=num_bins, bandwidth, blocks, bounds) (figures.py:95-98):
+ * KDEpy's FFTKDE = linear binning of the points onto the num_bins^d grid, convolution of the grid with the kernel,
+ * FES = -kB T log(density + eps).  The streaming stage is the binning: each of the n points (row-major float64, row
+ * stride ldp, the d <= 2 columns cols_h) spreads unit weight over the 2^d grid nodes around it.  grid_d receives the
+ * bins^d node weights (sum = points inside the bounds; d = 2: grid[i][j], i along the first column); outside_h the
+ * number of points outside [lo, hi] (ignored).  Deterministic (64-bit fixed-point accumulation).  The d-dimensional
+ * convolution on the small grid and the logarithm stay with the caller (statistics.compute_fes). */
+size_t dcv_linear_binning_workspace(int32_t d, int32_t bins);
+int dcv_linear_binning(const double* P_d, int64_t n, int64_t ldp, int32_t d, const int32_t* cols_h, const double* lo_h,
+                       const double* hi_h, int32_t bins, double* grid_d, int64_t* outside_h, void* ws_d, size_t ws_bytes, void* stream);
+
 /* Replaces statistics.find_centroids, statistics.py:370-377: for each of the k centroids the
  * index of the nearest of ALL n points under np.linalg.norm (ties -> lowest index).
  * best_d receives k pairs [distance (float64) | row (float64-encoded int64 is avoided:

@@ -241,3 +241,30 @@ def test_nearest_rows_wide_d():
         C = np.round(rng.uniform(-1, 1, (5, d)), 3)
         _, rows = hip.nearest_rows(dev(P), dev(C))
         np.testing.assert_array_equal(rows.cpu().numpy(), oc.find_centroid_rows(P, C))
+
+
+@pytest.mark.parametrize("d,bins,blocks", [(1, 150, 1), (2, 100, 1), (2, 64, 4), (1, 5000, 1)])
+def test_fes_binned_kde_matches_oracle(d, bins, blocks):
+    """f4, FES half: dcv_linear_binning + statistics.compute_fes against the NumPy restatement of the same binned KDE
+    (oracle/fes.py): node weights to 1e-9 (64-bit fixed-point accumulation, 2^-36 per contribution), FES to 1e-6 kJ/mol;
+    identical grids from two runs (integer atomics commute)."""
+    from deep_cartograph_amd import hip, statistics
+    from oracle import fes as ofes
+
+    rng = np.random.Generator(np.random.PCG64(11))
+    X = np.concatenate([rng.normal(-0.4, 0.12, (40_000, d)), rng.normal(0.45, 0.2, (60_000, d))]).clip(-1.2, 1.2)
+    lo, hi = [-1.0] * d, [1.0] * d
+    P = torch.from_numpy(X).cuda()
+    w1, out1 = hip.linear_binning(P, list(range(d)), lo, hi, bins)
+    w2, _ = hip.linear_binning(P, list(range(d)), lo, hi, bins)
+    assert torch.equal(w1, w2)
+    exp = ofes.linear_binning(X, lo, hi, bins)
+    assert out1 == int(np.sum(np.any((X < -1.0) | (X > 1.0), axis=1)))
+    np.testing.assert_allclose(w1.cpu().numpy(), exp, atol=1e-9 * X.shape[0])
+    fes, grid, bounds, err = statistics.compute_fes(X, 300.0, 0.05, bins, blocks=blocks, bounds=list(zip(lo, hi)))
+    assert fes.shape == (bins,) * d and err.shape == fes.shape and abs(fes.min()) < 1e-12
+    if blocks == 1:
+        ref = ofes.binned_fes(X, 300.0, 0.05, bins, lo, hi)
+        np.testing.assert_allclose(fes, ref, atol=1e-6)
+    else:
+        assert np.all(err >= 0) and np.isfinite(err).all()

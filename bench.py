@@ -101,6 +101,8 @@ class Fit:
     """The Deep-TICA fit loop of one rank at a given global batch: K optimiser steps over consecutive batches of the
     resident matrix (lengths [0.8, 0.2], sequential split, no shuffling), the validation pass at every epoch boundary."""
 
+    PRIME = 30   # untimed priming steps in front of the W warm-up steps of every run()
+
     def __init__(self, hip, dist, Xn, dims, acts, lag, global_batch, world, lr, linears, n_local):
         self.hip, self.dist, self.Xn, self.dims, self.lag = hip, dist, Xn, dims, lag
         self.gb = global_batch
@@ -140,7 +142,9 @@ class Fit:
         profile {(layer, kind): (total ms, launches)}, log records)."""
         eng = self.eng
         n_val = (steps // self.steps_per_epoch + 2) * (self.val_steps + 1)
-        eng.reset_log((steps + warmup) * 2 + n_val + 16)
+        eng.reset_log((steps + warmup + self.PRIME) * 2 + n_val + 16)
+        for i in range(self.PRIME):   # untimed, before the W warm-up steps: code-object loads of every kernel variant, clock ramp
+            self.train_step(i)
         for i in range(warmup):
             self.train_step(i)
         self.barrier()

@@ -113,6 +113,29 @@ int main(int argc, char** argv) {
     CK(hipMemset(Hb, 0, (size_t)R * H1 * 4));
     hipStream_t s = 0;
     const int it = argc > 2 ? atoi(argv[2]) : 20;
+    if (argc > 3 && !strcmp(argv[3], "cov")) {   // lagged covariance: X[R,256]^T x (X, X shifted by 10 rows), two B operands
+        const int Fc = 256;
+        const int64_t P = R - 10;
+#ifdef DCV_COVCFG
+        using CovCfg = DCV_COVCFG;
+#else
+        using CovCfg = CfgCovT<false>;
+#endif
+        for (int64_t kc : {2048, 4096}) {
+            int64_t kk = kc;
+            for (int64_t c = kc; c >= kc / 2; c -= 32) if (((P + c - 1) / c) % 8 == 0) { kk = c; break; }
+            const int64_t splits = (P + kk - 1) / kk;
+            float* cslab;
+            CK(hipMalloc(&cslab, (size_t)splits * 2 * Fc * Fc * 4));
+            Operand op = make_operand(X, Fc, Fc);
+            EpiSlab epi{cslab, Fc, Fc, 2, 0, true, splits};
+            double ms = time_ms([&] { launch_gemm_cfg<kTN, CovCfg, 2, EpiSlab>(op, op, 10, Fc, Fc, P, kk, epi, s); }, it);
+            printf("cov TN 2B kc=%5lld splits=%lld %8.1f us  %6.1f TF\n", (long long)kk, (long long)splits, ms * 1e3, 4.0 * P * Fc * Fc / ms / 1e9);
+            dump_stamps("cov", 1024);
+            CK(hipFree(cslab));
+        }
+        return 0;
+    }
     {   // L0 forward: [R,512] x [256,512]^T
         Operand A = make_operand(X, F, F), B = make_operand(W1, F, F);
         EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};

@@ -105,6 +105,11 @@ struct Operand {
     RowMap rows;
     const float* shift;  // per-(non-contraction)-column value subtracted on load (KMAJOR only), or null
     int vec_ok;          // 16-byte loads legal (alignment part; extents are checked at launch)
+    // Pre-split operand (contraction-contiguous kinds only; see "plane operands" below): p points at the three bf16
+    // planes of the matrix, ld and pstride are in float units (2 bf16 each): plane q of (row r, contraction index k)
+    // is the bf16 at ((const __bf16*)(p + r * ld + q * pstride))[k].
+    int planes = 0;
+    int64_t pstride = 0;
 };
 
 struct GemmDims {
@@ -112,16 +117,32 @@ struct GemmDims {
     int64_t k_chunk;  // TN: contraction rows per blockIdx.z (K for the others)
     int tiles_m, tiles_n;
     int xcd_remap;    // XCD-aware block -> tile map enabled (launch-time decision)
+    // Ragged last row tile of a row-parallel product (NT / NN) whose workgroup count just exceeds the CU count: that
+    // tile's contraction is cut into tail_split chunks of k_chunk, one extra (short-lived) workgroup each, instead of
+    // one full-length workgroup that would share a CU's SIMDs with a regular one for the whole launch.  Every chunk
+    // leaves its raw accumulators in tail_ws; the last to arrive (ticket in tail_cnt) adds them up in chunk order and
+    // runs the epilogue.  0 = off.
+    int tail_split = 0;
+    float* tail_ws = nullptr;
+    unsigned* tail_cnt = nullptr;
 };
 
 // NBUF: LDS stage buffers of the pure-DMA main loop (a ring: NBUF-1 stages in flight ahead of the
 // one being multiplied); the register-staged loop always double-buffers in the first two.
 // SPLIT: FP32-accurate products on the BF16 matrix pipe (see split3 / mfma16 below) instead of the
 // FP32-input MFMA.
-template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_, int NBUF_ = 2, bool SPLIT_ = false>
+// PL (SPLIT, NT products only): bit 0 / bit 1 = the A / B operand arrives pre-split into its three bf16 planes
+// (Operand::planes), so its share of the in-register split -- the vector-ALU work that bounds the SPLIT flavour --
+// disappears from the main loop.
+template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_, int NBUF_ = 2, bool SPLIT_ = false, int PL_ = 0>
 struct TileCfg {
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, FM = FM_, FN = FN_, KB = KB_, NBUF = NBUF_;
     static constexpr bool SPLIT = SPLIT_;
+    static constexpr int PL = PL_;
+    static_assert(PL == 0 || SPLIT, "plane operands belong to the split flavour");
+    // LDS floats of one stage: an fp32 tile is [T][KB] floats, a plane tile three [T][KB/2] images
+    static constexpr int A_SZ = (PL & 1) ? 3 * (WAVES_M_ * FM_ * 32) * (KB_ / 2) : (WAVES_M_ * FM_ * 32) * KB_;
+    static constexpr int B_SZ = (PL & 2) ? 3 * (WAVES_N_ * FN_ * 32) * (KB_ / 2) : (WAVES_N_ * FN_ * 32) * KB_;
     static_assert(NBUF >= 2 && NBUF <= 8, "NBUF");
     static constexpr int TM = WAVES_M * FM * 32;
     static constexpr int TN = WAVES_N * FN * 32;
@@ -230,6 +251,9 @@ struct MMajorStage {
     bool all_rows;          // every row of the tile is in range (workgroup-uniform)
     bool affine;            // the tile's rows are row0 + m: no gather, not astride the x_t / x_lag seam
 
+    // CLAMP (kernels with plane operands: pure LDS-DMA, no register-staged loop): rows past the end read the last
+    // valid row instead of being zero-filled -- they only feed output rows the epilogue masks
+    template <bool CLAMP = false>
     __device__ __forceinline__ void init(const Operand& op, int64_t m0, int64_t m_end, int t) {
         const int row0 = t / CPR;
         kofs = ((t % CPR) ^ ((row0 / RPBR) % CPR)) * 4;
@@ -238,7 +262,8 @@ struct MMajorStage {
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const int u = t + 256 * i;
-            const int64_t m = m0 + u / CPR;
+            int64_t m = m0 + u / CPR;
+            if constexpr (CLAMP) m = m < m_end ? m : m_end - 1;
             const bool ok = (UNITS % 256 == 0 || u < UNITS) && m < m_end;
             src[i] = ok ? op.p + op.rows.template get<GATHER>(m) * op.ld + kofs : nullptr;
             voff[i] = (unsigned)(((int64_t)(u / CPR) * op.ld + kofs) * 4);
@@ -482,18 +507,35 @@ __device__ __forceinline__ void vm_wait_younger(int64_t younger) {
 template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
 __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, int64_t lag2, const GemmDims& d,
                                            int tile_m, int tile_n, int64_t k_begin, int64_t k_end, float* lds,
-                                           Epi& epi) {
+                                           Epi& epi, int tail_chunk = -1) {
     constexpr int TM = Cfg::TM, TN = Cfg::TN, KB = Cfg::KB, FM = Cfg::FM, FN = Cfg::FN;
-    constexpr int A_SZ = TM * KB, B_SZ = TN * KB;
+    constexpr int A_SZ = Cfg::A_SZ, B_SZ = Cfg::B_SZ;
     constexpr int STAGE = A_SZ + NB * B_SZ;
     constexpr bool A_MM = (MODE == kNT || MODE == kNN);
     constexpr bool B_MM = (MODE == kNT);
+    // ---- plane operands (Cfg::PL): the operand was split into its three bf16 planes ahead of time (a matrix that is
+    // constant over many products: the training set, the weights between optimiser steps).  A plane tile is three
+    // MMAJOR images of [T][KB/2] floats (= [T][KB] bf16) with the same chunk swizzle, filled by LDS-DMA only; a lane's
+    // 16-byte fragment read IS the bf16x8 operand of v_mfma_f32_32x32x16_bf16, bit-identical to what split3 would
+    // have produced from the fp32 value.  Such kernels have no register-staged loop: the launch guarantees K % KB == 0
+    // and 16-byte loads, and ragged row tiles read clamped rows (MMajorStage::init<true>).
+    constexpr int PL = Cfg::PL;
+    constexpr bool PA = (PL & 1) != 0, PB = (PL & 2) != 0;
+    static_assert(PL == 0 || (MODE == kNT && NB == 1 && VEC && Cfg::SPLIT), "plane operands: NT products of the split flavour");
+    constexpr int KF = KB / 2;           // floats per row of a plane image
+    constexpr int KA = PA ? KF : KB, KBB = PB ? KF : KB;
+    constexpr int NPA = PA ? 3 : 1, NPB = PB ? 3 : 1;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
     const int wm = (wave / Cfg::WAVES_N) * FM * 32;
     const int wn = (wave % Cfg::WAVES_N) * FN * 32;
     const int64_t m0 = (int64_t)tile_m * TM, n0 = (int64_t)tile_n * TN;
+#ifdef DCV_ABL_SAMETILE   // diagnostic (wrong results): every workgroup streams the first few row tiles of A -- all cache hits
+    const int64_t m0_ld = (int64_t)(tile_m % DCV_ABL_SAMETILE) * TM;
+#else
+    const int64_t m0_ld = m0;
+#endif
 
     f32x16 acc[NB][FM][FN];
 #pragma unroll
@@ -505,13 +547,13 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[b][i][j][e] = 0.f;
 
-    MMajorStage<TM, KB, VEC, GATHER> am;
+    MMajorStage<TM, KA, VEC, GATHER> am;
     KMajorStage<TM, KB, VEC, GATHER> ak;
-    MMajorStage<TN, KB, VEC, GATHER> bm;
+    MMajorStage<TN, KBB, VEC, GATHER> bm;
     KMajorStage<TN, KB, VEC, GATHER> bk[NB];
-    if constexpr (A_MM) am.init(A, m0, d.M, t);
+    if constexpr (A_MM) am.template init<PL != 0>(A, m0, d.M, t);
     else ak.init(A, m0, d.M, t);
-    if constexpr (B_MM) bm.init(B, n0, d.N, t);
+    if constexpr (B_MM) bm.template init<PL != 0>(B, n0, d.N, t);
     else {
 #pragma unroll
         for (int b = 0; b < NB; ++b) bk[b].init(B, n0, d.N, t);
@@ -540,8 +582,30 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     };
     // pure-DMA issue of the stage at k0 into ring buffer `buf`
     const unsigned ldsw = lds_addr_uniform(lds + (t & ~63) * 4);   // this wave's unit-0 slot of buffer 0
+    // plane kernels: an operand whose tile is in range and affine takes the batched form, any other (gathered rows,
+    // the x_t / x_lag seam, a ragged last row tile) per-thread pointers to clamped rows; workgroup-uniform choice
+    const bool pl_a_aff = am.affine && am.all_rows, pl_b_aff = bm.affine && bm.all_rows;
     auto glds_stage = [&](int64_t k0, int buf, int part = 3) {   // part: 1 = A operand, 2 = B operand(s)
-        if constexpr (GATHER) {   // per-thread 64-bit source pointers
+        if constexpr (PL != 0) {
+            const unsigned l0 = ldsw + (unsigned)(buf * STAGE) * 4u;
+            float* b = lds + buf * STAGE;
+            if (part & 1) {
+                const int64_t ka = PA ? k0 / 2 : k0;   // float offset inside a row
+#pragma unroll
+                for (int q = 0; q < NPA; ++q) {
+                    if (pl_a_aff) am.glds_affine(am.tile_base(A, m0_ld, ka) + q * A.pstride, l0 + (unsigned)(q * TM * KF) * 4u);
+                    else am.glds(ka + q * A.pstride, b + q * TM * KF, t);
+                }
+            }
+            if (part & 2) {
+                const int64_t kb = PB ? k0 / 2 : k0;
+#pragma unroll
+                for (int q = 0; q < NPB; ++q) {
+                    if (pl_b_aff) bm.glds_affine(bm.tile_base(B, n0, kb) + q * B.pstride, l0 + (unsigned)(A_SZ + q * TN * KF) * 4u);
+                    else bm.glds(kb + q * B.pstride, b + A_SZ + q * TN * KF, t);
+                }
+            }
+        } else if constexpr (GATHER) {   // per-thread 64-bit source pointers
             float* b = lds + buf * STAGE;
             if (part & 1) {
                 resolve_stage(k0);
@@ -558,7 +622,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         } else {                  // affine tiles: uniform base + constant unit offsets, no vector ALU
             const unsigned l0 = ldsw + (unsigned)(buf * STAGE) * 4u;
             if (part & 1) {
-                if constexpr (A_MM) am.glds_affine(am.tile_base(A, m0, k0), l0);
+                if constexpr (A_MM) am.glds_affine(am.tile_base(A, m0_ld, k0), l0);
                 else ak.glds_affine(ak.stage_base(A, k0, 0, m0), l0);
             }
             if (part & 2) {
@@ -688,12 +752,18 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     struct Frags8 {
         float a[FM][8];
         float b[NB][FN][8];
+        u32x4 ap[3][FM];       // plane operands: the fragment is the bf16x8 itself
+        u32x4 bp[3][FN];
     };
     auto read_frags8 = [&](Frags8& f, const float* la, const float* lb, int s) {
         const int h = lane >> 5;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            if constexpr (A_MM) {
+            if constexpr (PA) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    f.ap[q][i] = __builtin_bit_cast(u32x4, frag_mmajor_chunk<KF>(la + q * TM * KF, wm + i * 32, 2 * s + h, lane));
+            } else if constexpr (A_MM) {
                 const v4f u = frag_mmajor_chunk<KB>(la, wm + i * 32, 4 * s + 2 * h, lane);
                 const v4f v = frag_mmajor_chunk<KB>(la, wm + i * 32, 4 * s + 2 * h + 1, lane);
                 f.a[i][0] = u.x; f.a[i][1] = u.y; f.a[i][2] = u.z; f.a[i][3] = u.w;
@@ -707,7 +777,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                if constexpr (B_MM) {
+                if constexpr (PB) {
+#pragma unroll
+                    for (int q = 0; q < 3; ++q)
+                        f.bp[q][j] = __builtin_bit_cast(u32x4, frag_mmajor_chunk<KF>(lb + q * TN * KF, wn + j * 32, 2 * s + h, lane));
+                } else if constexpr (B_MM) {
                     const v4f u = frag_mmajor_chunk<KB>(lb, wn + j * 32, 4 * s + 2 * h, lane);
                     const v4f v = frag_mmajor_chunk<KB>(lb, wn + j * 32, 4 * s + 2 * h + 1, lane);
                     f.b[b][j][0] = u.x; f.b[b][j][1] = u.y; f.b[b][j][2] = u.z; f.b[b][j][3] = u.w;
@@ -732,17 +806,27 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 p.a3[i][e] = p.a1[i][e];
             }
 #else
-            split3(f.a[i], p.a1[i], p.a2[i], p.a3[i]);
+            if constexpr (PA) {
+                p.a1[i] = f.ap[0][i]; p.a2[i] = f.ap[1][i]; p.a3[i] = f.ap[2][i];
+            } else {
+                split3(f.a[i], p.a1[i], p.a2[i], p.a3[i]);
+            }
 #endif
         }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int j = 0; j < FN; ++j) split3(f.b[b][j], p.b1[b][j], p.b2[b][j], p.b3[b][j]);
+            for (int j = 0; j < FN; ++j) {
+                if constexpr (PB) {
+                    p.b1[b][j] = f.bp[0][j]; p.b2[b][j] = f.bp[1][j]; p.b3[b][j] = f.bp[2][j];
+                } else {
+                    split3(f.b[b][j], p.b1[b][j], p.b2[b][j], p.b3[b][j]);
+                }
+            }
     };
     // Makes the planes opaque at this point of the program: their split must have been computed by here (the compiler
     // otherwise sinks it to the first use, on the far side of a stage barrier).
-    auto pin_planes = [&](Planes& p) {
+    [[maybe_unused]] auto pin_planes = [&](Planes& p) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             asm volatile("" : "+v"(p.a1[i]), "+v"(p.a2[i]), "+v"(p.a3[i]));
@@ -854,7 +938,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // no reason to wait on the vector-memory counter inside the MFMA phase.  Whatever remains -- the
     // ragged last stage of such a workgroup, or every stage of an edge tile / scalar-load / covariance
     // shift workgroup -- runs the register-staged loop behind it.
-    const bool dense_ok = nst > 0 && stage_dense(k_begin) && affine_all();
+    const bool dense_ok = PL != 0 || (nst > 0 && stage_dense(k_begin) && affine_all());
     const int64_t nfull = dense_ok ? (k_end - k_begin) / KB : 0;
     if (nfull > 0) {
         const int64_t nst = nfull;   // stages of the ring loop
@@ -866,8 +950,8 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         // the barrier skew, the DMA issue and the LDS latency, so the matrix pipe does not drain at
         // stage boundaries even with one wave per SIMD.
         constexpr int NBUF = Cfg::NBUF;
-        constexpr int GL = (A_MM ? MMajorStage<TM, KB, VEC, GATHER>::PER : KMajorStage<TM, KB, VEC, GATHER>::PER) +
-                           NB * (B_MM ? MMajorStage<TN, KB, VEC, GATHER>::PER : KMajorStage<TN, KB, VEC, GATHER>::PER);  // DMA instructions per thread and stage
+        constexpr int GL = (A_MM ? NPA * MMajorStage<TM, KA, VEC, GATHER>::PER : KMajorStage<TM, KB, VEC, GATHER>::PER) +
+                           NB * (B_MM ? NPB * MMajorStage<TN, KBB, VEC, GATHER>::PER : KMajorStage<TN, KB, VEC, GATHER>::PER);  // DMA instructions per thread and stage
         static_assert((NBUF - 2) * GL <= 63, "vmcnt range");
         static_assert(Cfg::SPLIT || G % 2 == 0, "fragment double buffer parity");
 #pragma unroll
@@ -1049,7 +1133,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         DCV_STAMP_RT(5);
     }
     const int64_t k_rem = k_begin + nfull * KB;
-    const int64_t nrem = (k_end - k_rem + KB - 1) / KB;
+    const int64_t nrem = PL != 0 ? 0 : (k_end - k_rem + KB - 1) / KB;
     if (nrem > 0) {
         resolve_stage(k_rem);
         load_stage(k_rem);
@@ -1067,6 +1151,49 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             compute_stage(cur);
             if (more) store_stage(nxt);
             __syncthreads();
+        }
+    }
+    if constexpr (MODE != kTN && NB == 1) {
+        if (tail_chunk >= 0) {   // workgroup-uniform: one contraction chunk of the ragged last row tile (GemmDims::tail_split)
+            constexpr int NACC = FM * FN * 16;
+            const int S = d.tail_split;
+            float* ws = d.tail_ws + (int64_t)tile_n * S * NACC * 256;
+            float* mine = ws + (int64_t)tail_chunk * NACC * 256 + t;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) mine[((i * FN + j) * 16 + e) * 256] = acc[0][i][j][e];
+            __threadfence();
+            __syncthreads();
+            int* flag = reinterpret_cast<int*>(lds);
+            if (t == 0) {
+                const unsigned prev = atomicAdd(d.tail_cnt + tile_n, 1u);
+                const bool last = prev == (unsigned)(S - 1);
+                if (last) d.tail_cnt[tile_n] = 0u;   // ready for the next launch on this stream
+                *flag = last ? 1 : 0;
+            }
+            __syncthreads();
+            const bool last = *flag != 0;
+            __syncthreads();   // the flag word is part of the epilogue's staging area
+            if (!last) return;
+            __threadfence();
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[0][i][j][e] = 0.f;
+            for (int c = 0; c < S; ++c) {   // chunk order, whoever arrived last: the sum is reproducible
+                const float* part = ws + (int64_t)c * NACC * 256 + t;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[0][i][j][e] += __builtin_nontemporal_load(part + ((i * FN + j) * 16 + e) * 256);
+            }
         }
     }
 #ifdef DCV_ABL_NOEPI
@@ -1234,7 +1361,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 
 template <class Cfg, int NB>
 constexpr size_t gemm_lds_bytes() {
-    return (size_t)Cfg::NBUF * (Cfg::TM * Cfg::KB + NB * Cfg::TN * Cfg::KB) * sizeof(float);
+    return (size_t)Cfg::NBUF * (Cfg::A_SZ + NB * Cfg::B_SZ) * sizeof(float);
 }
 
 }  // namespace dcv

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
     // L2); the workgroups that read the same rows -- the column tiles of one row tile (NT / NN), the
     // output tiles of one contraction chunk (TN) -- are therefore given ids that are congruent mod 8.
     // Placement is a speed heuristic only: any dispatch order computes the same result.
-    int tile_m, tile_n;
+    int tile_m, tile_n, tail_chunk = -1;
     int64_t k_begin = 0, k_end = d.K;
     if constexpr (MODE == kTN) {
         const int T = d.tiles_m * d.tiles_n;
@@ -324,7 +324,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
         if constexpr (std::is_same<Epi, EpiSlab>::value) epi.z = split;
     } else {
         int tile = blockIdx.x;
-        if (d.xcd_remap) {
+        const int regular = d.tail_split > 0 ? (d.tiles_m - 1) * d.tiles_n : d.tiles_m * d.tiles_n;
+        if (tile >= regular) {   // a contraction chunk of the ragged last row tile
+            const int j = tile - regular;
+            tile_m = d.tiles_m - 1;
+            tile_n = j % d.tiles_n;
+            tail_chunk = j / d.tiles_n;
+            k_begin = (int64_t)tail_chunk * d.k_chunk;
+            k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
+        } else if (d.xcd_remap) {
             const int xcd = tile & 7, q = tile >> 3;
             tile_n = q % d.tiles_n;
             tile_m = (q / d.tiles_n) * 8 + xcd;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t
             tile_n = tile - tile_m * d.tiles_n;
         }
     }
-    gemm_block<MODE, Cfg, NB, VEC, GATHER, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi);
+    gemm_block<MODE, Cfg, NB, VEC, GATHER, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi, tail_chunk);
 }
 
 // Tile configurations, each in two arithmetic flavours (template argument S): the FP32-input MFMA
@@ -367,15 +375,29 @@ static int launch_gemm_vec(const Operand& A, const Operand& B, int64_t lag2, con
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)((int64_t)d.tiles_m * d.tiles_n), 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
+    const int64_t blocks = d.tail_split > 0 ? (int64_t)(d.tiles_m - 1 + d.tail_split) * d.tiles_n : (int64_t)d.tiles_m * d.tiles_n;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
     DCV_CHECK_LAUNCH();
     return DCV_OK;
+}
+
+// Workspace of the contraction-split tail tile (GemmDims::tail_split): owned by the caller, one per stream of launches
+struct TailWs {
+    float* ws = nullptr;       // cap floats
+    unsigned* cnt = nullptr;   // max_tiles_n zero-initialised tickets
+    int64_t cap = 0;
+    int max_tiles_n = 0;
+};
+constexpr int kTailMaxSplit = 8;
+inline bool tail_split_enabled() {
+    static const bool on = [] { const char* e = getenv("DCV_TAIL_KSPLIT"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // tiles_m_out (optional) receives the number of row tiles (= bias partial blocks of EpiActGrad)
 template <int MODE, class Cfg, int NB, class Epi>
 static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int64_t M, int64_t N, int64_t K,
-                           int64_t k_chunk, const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
+                           int64_t k_chunk, const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr, const TailWs* tw = nullptr) {
     GemmDims d;
     d.M = M;
     d.N = N;
@@ -390,6 +412,26 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
         const int64_t nsplit = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
         // bijective only when the remapped index is a multiple of 8
         d.xcd_remap = env && ((MODE == kTN) ? (nsplit % 8 == 0) : (d.tiles_m % 8 == 0 && d.tiles_n > 1));
+        if constexpr (MODE != kTN && NB == 1) {
+            // Ragged last row tile: worth cutting along the contraction when it is what pushes the workgroup count past a
+            // multiple of the CU count on a small grid (8202 rows in 64-row tiles x 2 column tiles = 258 workgroups on
+            // 256 CUs: two CUs would run two full-length workgroups on the same SIMDs, 1.4 x the launch time).
+            const int64_t stages = K / Cfg::KB, ncu = num_cus();
+            const int64_t all = (int64_t)d.tiles_m * d.tiles_n, regular = all - d.tiles_n;
+            if (tw && tw->ws && tail_split_enabled() && M % Cfg::TM != 0 && d.tiles_m >= 2 && K % Cfg::KB == 0 && stages >= 4 &&
+                all <= 4 * ncu && cdiv(all, ncu) > cdiv(regular, ncu) && d.tiles_n <= tw->max_tiles_n) {
+                const int64_t want = stages / 2 < kTailMaxSplit ? stages / 2 : kTailMaxSplit;
+                const int64_t kc = cdiv(stages, want) * Cfg::KB;
+                const int64_t S = cdiv(K, kc);
+                if (S >= 2 && (int64_t)d.tiles_n * S * Cfg::FM * Cfg::FN * 16 * 256 <= tw->cap) {
+                    d.tail_split = (int)S;
+                    d.k_chunk = kc;
+                    d.tail_ws = tw->ws;
+                    d.tail_cnt = tw->cnt;
+                    d.xcd_remap = env && ((d.tiles_m - 1) % 8 == 0 && d.tiles_n > 1);
+                }
+            }
+        }
     }
     const int64_t splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
     const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
@@ -417,24 +459,24 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
 // batches of a multi-GPU run); TN products get their parallelism from the split count instead.
 template <int MODE, bool S, class Epi>
 static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
-                            const Epi& epi, hipStream_t s, int* tiles_m_out) {
+                            const Epi& epi, hipStream_t s, int* tiles_m_out, const TailWs* tw = nullptr) {
 #ifdef DCV_BIGCFG
     using Big = CfgBig;
 #else
     using Big = CfgBigT<S>;
 #endif
 #ifdef DCV_FORCE_BIG   // diagnostic (tools/gemm_bench): every product takes the DCV_BIGCFG tile, whatever its extents
-    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 #endif
-    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
-    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
     if constexpr (MODE != kTN) {
         const int64_t want = 2 * (int64_t)num_cus();
         const int64_t tn = cdiv(N, 128);
         if (cdiv(M, 128) * tn < want) {
-            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
-            if (cdiv(M, 64) * tn < want / 2) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
-            return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+            if (cdiv(M, 64) * tn < want / 2) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+            return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
         }
     }
     if constexpr (MODE == kTN) {
@@ -442,20 +484,121 @@ static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64
         // four times the workgroups with 64 x 64 tiles (measured on the 128 x 256 x 8202 product: 17.2 -> 10.6 us)
         const int64_t nsplit = cdiv(K, k_chunk > 0 ? k_chunk : K);
         if (cdiv(M, 128) * cdiv(N, 128) * nsplit < (int64_t)num_cus() / 2)
-            return launch_gemm_cfg<MODE, CfgQuarterT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+            return launch_gemm_cfg<MODE, CfgQuarterT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
     }
-    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out);
+    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 }
 
 template <int MODE, class Epi>
 static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
-                       const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr) {
+                       const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr, const TailWs* tw = nullptr) {
 #ifdef DCV_BIGCFG
-    return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out);
+    return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 #else
-    if (gemm_split()) return launch_gemm_mode<MODE, true, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out);
-    return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out);
+    if (gemm_split()) return launch_gemm_mode<MODE, true, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+    return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 #endif
+}
+
+// ------------------------------------------------------------------ plane operands (TileCfg::PL)
+// Plane form of an fp32 matrix [rows][cols]: row r is [plane 1 | plane 2 | plane 3], each Kp = round_up(cols, 32) bf16
+// (zero padded), the pieces of split3 -- x = p1 + p2 + p3 exactly, truncation split.  In float units the row pitch is
+// 3 * Kp / 2 and the plane stride Kp / 2.  The engine keeps the training matrix and the weights in this form next to
+// the fp32 originals: the split is then paid once per matrix instead of once per use inside the product's main loop.
+__host__ __device__ inline int64_t planes_kp(int64_t cols) { return (cols + 31) / 32 * 32; }
+__host__ __device__ inline int64_t planes_ld(int64_t cols) { return 3 * planes_kp(cols) / 2; }        // floats
+__host__ __device__ inline int64_t planes_pstride(int64_t cols) { return planes_kp(cols) / 2; }       // floats
+inline size_t planes_bytes(int64_t rows, int64_t cols) { return (size_t)rows * (size_t)planes_ld(cols) * sizeof(float); }
+// TRANS: dst row = src column (the planes of the transpose; small matrices only -- the loads are strided)
+template <bool TRANS>
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ src, int64_t ld, int64_t rows, int64_t cols,
+                                                           float* __restrict__ dst, int64_t rows_out) {
+    const int64_t orows = TRANS ? cols : rows, ocols = TRANS ? rows : cols;   // extents of the matrix being written
+    const int64_t kp8 = planes_kp(ocols) / 8, ldp = planes_ld(ocols), ps = planes_pstride(ocols);
+    const int64_t total = rows_out * kp8;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / kp8, g = i - r * kp8;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int64_t k = 8 * g + e;
+            x[e] = (r < orows && k < ocols) ? (TRANS ? src[k * ld + r] : src[r * ld + k]) : 0.f;
+        }
+        u32x4 p1, p2, p3;
+        split3(x, p1, p2, p3);
+        float* o = dst + r * ldp + g * 4;
+        *reinterpret_cast<u32x4*>(o) = p1;
+        *reinterpret_cast<u32x4*>(o + ps) = p2;
+        *reinterpret_cast<u32x4*>(o + 2 * ps) = p3;
+    }
+}
+// rows_out >= (TRANS ? cols : rows): rows past the matrix are written as zeros
+template <bool TRANS>
+static int launch_split_planes(const float* src, int64_t ld, int64_t rows, int64_t cols, float* dst, int64_t rows_out, hipStream_t s) {
+    const int64_t ocols = TRANS ? rows : cols;
+    const int64_t total = rows_out * (planes_kp(ocols) / 8);
+    if (total <= 0) return DCV_OK;
+    int64_t blocks = cdiv(total, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(split_planes_kernel<TRANS>, dim3((unsigned)blocks), dim3(256), 0, s, src, ld, rows, cols, dst, rows_out);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+inline Operand make_plane_operand(const float* planes, int64_t cols, const RowMap& rows = RowMap{nullptr, 0, 0, 0}) {
+    Operand o;
+    o.p = planes;
+    o.ld = planes_ld(cols);
+    o.rows = rows;
+    o.shift = nullptr;
+    o.vec_ok = (reinterpret_cast<uintptr_t>(planes) & 15) == 0;
+    o.planes = 1;
+    o.pstride = planes_pstride(cols);
+    return o;
+}
+
+// Tile shapes of the plane kernels (LDS per workgroup in brackets):
+//   PL = 3 (both operands pre-split, no vector-ALU work in the main loop):
+//          128 x 128, 16-deep stages, ring of 3 [72 KiB] ; 64 x 128, 32-deep stages [72 KiB]
+//   PL = 2 (B pre-split, A split in registers): 128 x 128 [80 KiB] ; 64 x 128 [64 KiB]
+#ifdef DCV_PL3_BIG   // diagnostic override (tools/planes_bench): KB, NBUF of the PL = 3 128 x 128 tile
+template <int PL> using CfgPlBig = TileCfg<2, 2, 2, 2, PL == 3 ? DCV_PL3_BIG : 32, 2, true, PL>;
+#else
+template <int PL> using CfgPlBig = TileCfg<2, 2, 2, 2, PL == 3 ? 16 : 32, PL == 3 ? 3 : 2, true, PL>;
+#endif
+template <int PL> using CfgPlHalf = TileCfg<2, 2, 1, 2, 32, 2, true, PL>;
+
+// NT product with plane operands: C[M,N] = A[M,K] . B[N,K]^T.  Returns DCV_EINVAL-free "not applicable" (1) when the
+// shape or the operands do not qualify -- the caller then takes the fp32-operand kernel -- and a DCV_E* (< 0) on error.
+template <int PL, class Epi>
+static int launch_gemm_planes(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const Epi& epi, hipStream_t s,
+                              int* tiles_m_out = nullptr) {
+    static_assert(PL >= 1 && PL <= 3, "PL");
+    const bool a_ok = (PL & 1) ? (A.planes == 1 && A.pstride % 4 == 0) : (A.planes == 0);
+    const bool b_ok = (PL & 2) ? (B.planes == 1 && B.pstride % 4 == 0) : (B.planes == 0);
+    if (!a_ok || !b_ok || !A.vec_ok || !B.vec_ok || A.ld % 4 != 0 || B.ld % 4 != 0) return 1;
+    if (K % 32 != 0 || K < 64 || N <= 32 || M <= 32) return 1;
+    if (A.rows.idx != nullptr || B.rows.idx != nullptr || A.shift || B.shift) return 1;
+    if (A.ld >= kMaxAffineLd || B.ld >= kMaxAffineLd) return 1;
+    auto go = [&](auto cfg) -> int {
+        using Cfg = decltype(cfg);
+        GemmDims d;
+        d.M = M; d.N = N; d.K = K; d.k_chunk = K;
+        d.tiles_m = (int)cdiv(M, Cfg::TM);
+        d.tiles_n = (int)cdiv(N, Cfg::TN);
+        if (tiles_m_out) *tiles_m_out = d.tiles_m;
+        static int env = -1;
+        if (env < 0) { const char* e = getenv("DCV_XCD_REMAP"); env = e ? atoi(e) : 1; }
+        d.xcd_remap = env && d.tiles_m % 8 == 0 && d.tiles_n > 1;
+        const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
+        DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31), "gemm: grid out of range (tiles=%lld)", (long long)tiles);
+        return launch_gemm_vec<kNT, Cfg, 1, true, false, Epi>(A, B, 0, d, 1, epi, s);
+    };
+    const int64_t want = 2 * (int64_t)num_cus();
+#ifdef DCV_PL_FORCE_BIG
+    return go(CfgPlBig<PL>{});
+#endif
+    if (cdiv(M, 128) * cdiv(N, 128) < want) return go(CfgPlHalf<PL>{});
+    return go(CfgPlBig<PL>{});
 }
 
 inline Operand make_operand(const float* p, int64_t ld, int64_t inner_extent, const RowMap& rows = RowMap{nullptr, 0, 0, 0},

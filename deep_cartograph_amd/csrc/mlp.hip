@@ -49,8 +49,7 @@ struct dcv_mlp {
     double momentum_rt;        // beta1 (Adam family) or momentum (SGD, RMSprop): dcv_mlp_set_momentum
     bool any_drop;             // some layer has dropout p > 0
     bool fwd_train;            // the last forward ran in training mode (dropout active): backward must agree
-    hipStream_t aux;           // side stream for the tail-tile launches of row-tiled products (tail_main_rows)
-    hipEvent_t ev_fork, ev_join;
+    dcv::TailWs tail;          // workspace of the contraction-split tail tile of row-tiled products (gemm.h: GemmDims::tail_split)
     void (*upper_cb)(void*);   // data-parallel overlap hook (dcv_mlp_set_upper_grads_callback) or null
     void* upper_cb_user;
     bool head_done;            // the last forward already ran the d x d loss head inside its statistics launch (one-GPU steps)
@@ -1163,9 +1162,7 @@ static void mlp_free(dcv_mlp* m) {
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
     for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); }
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
-    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
-    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
-    if (m->aux) (void)hipStreamDestroy(m->aux);
+    f(m->tail.ws); f(m->tail.cnt);
     for (int i = 0; i < 4; ++i) if (m->gexec[i]) (void)hipGraphExecDestroy(m->gexec[i]);
     delete m;
 }
@@ -1242,8 +1239,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->head_done = false;
     m->upper_cb = nullptr;
     m->upper_cb_user = nullptr;
-    m->aux = nullptr;
-    m->ev_fork = m->ev_join = nullptr;
+    m->tail = dcv::TailWs{};
     m->drop_step = 0;
     m->cur_step = 0;
     m->prof_level = m->prof_cap = m->prof_step = 0;
@@ -1331,9 +1327,13 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         for (int i = 0; i < dl; ++i) eye[(size_t)i * dl + i] = 1.f;
         e = hipMemcpy(m->ident, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->aux, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
+    if (e == hipSuccess) {   // tail-tile workspace: up to 8 column tiles x kTailMaxSplit chunks of a 128 x 128 tile's accumulators
+        m->tail.max_tiles_n = 8;
+        m->tail.cap = (int64_t)m->tail.max_tiles_n * kTailMaxSplit * 64 * 256;
+        e = hipMalloc(reinterpret_cast<void**>(&m->tail.ws), (size_t)m->tail.cap * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->tail.cnt), m->tail.max_tiles_n * sizeof(unsigned));
+        if (e == hipSuccess) e = hipMemset(m->tail.cnt, 0, m->tail.max_tiles_n * sizeof(unsigned));
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("dcv_mlp_create: initialisation failed: %s", hipGetErrorString(e));
@@ -1470,52 +1470,6 @@ static bool next_layer_fusable(const dcv_mlp* m, int l) {
     return m->layers[l + 1].out <= 8 && m->layers[l].out <= 128;
 }
 
-// Tail tile of a row-tiled product on a small grid.  8192 + lag rows are 129 tiles of 64 rows: with two column tiles 258
-// workgroups on 256 CUs, and the two workgroups of the 10-row tail tile share the SIMDs of a CU with two others -- the
-// launch takes 1.35 x as long as 256 workgroups would (tools/gemm_bench: 31.7 vs 23.4 us).  Diagnostic,
-// OFF by default (DCV_TAIL_SPLIT=1 enables): when the tail rows (<= 32) are what pushes the grid into another round of
-// the chip they go out as a launch of their own (narrow tile, 1-2 workgroups).  Measured at the contract batch it does
-// not pay: the narrow launch costs more than the 8 us it saves when it runs on the same stream (layer-0 forward
-// 36.5 -> 48 us), and on a side stream the event fork / join costs ~20 us per step (-> 58 us).  Returns the rows of the
-// main launch, or 0 for no split.
-static int nt_tile_rows(int64_t M, int64_t N) {   // the tile height launch_gemm_mode picks for a row-parallel product
-    if (N <= 32) return 128;
-    if (M <= 32) return 32;
-    const int64_t want = 2 * (int64_t)num_cus(), tn = cdiv(N, 128);
-    if (cdiv(M, 128) * tn < want) {
-        if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return 64;
-        if (cdiv(M, 64) * tn < want / 2) return 32;
-        return 64;
-    }
-    return 128;
-}
-static int64_t tail_main_rows(int64_t M, int64_t N) {
-    static const bool on = [] { const char* e = getenv("DCV_TAIL_SPLIT"); return e && e[0] == '1'; }();
-    if (!on || N <= 32 || M <= 64) return 0;
-    const int tm = nt_tile_rows(M, N);
-    const int64_t main_rows = M / tm * tm, tail = M - main_rows;
-    if (tail == 0 || tail > 32 || main_rows == 0 || nt_tile_rows(main_rows, N) != tm) return 0;
-    const int64_t tn = cdiv(N, 128), ncu = num_cus();
-    const int64_t wg_main = main_rows / tm * tn, wg_all = cdiv(M, tm) * tn;
-    if (wg_all > 4 * ncu || (wg_all - 1) / ncu == (wg_main - 1) / ncu) return 0;   // the tail does not open a new round
-    return main_rows;
-}
-static int fork_aux(dcv_mlp* m, hipStream_t s) {
-    DCV_CHECK_HIP(hipEventRecord(m->ev_fork, s));
-    DCV_CHECK_HIP(hipStreamWaitEvent(m->aux, m->ev_fork, 0));
-    return DCV_OK;
-}
-static int join_aux(dcv_mlp* m, hipStream_t s) {
-    DCV_CHECK_HIP(hipEventRecord(m->ev_join, m->aux));
-    DCV_CHECK_HIP(hipStreamWaitEvent(s, m->ev_join, 0));
-    return DCV_OK;
-}
-static Operand rows_from(const Operand& A, int64_t r) {   // the same operand starting r logical rows further down
-    Operand o = A;
-    if (A.rows.idx == nullptr && A.rows.half == 0) o.rows.row0 += r;
-    return o;
-}
-
 // forward through layers [0, n_run) for `rows` logical rows
 // (dropout follows m->fwd_train, which the callers set: training forward on, everything else off)
 static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& rows_map, int64_t rows, int n_run, hipStream_t s,
@@ -1534,11 +1488,11 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             if (nx.out <= 4) {
                 EpiBiasActHead<4> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
                 epi.drop = drop_cfg(m, l);
-                rc = launch_gemm<kNT, EpiBiasActHead<4>>(A, B, rows, p.out, p.in, 0, epi, s);
+                rc = launch_gemm<kNT, EpiBiasActHead<4>>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
             } else {
                 EpiBiasActHead<8> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
                 epi.drop = drop_cfg(m, l);
-                rc = launch_gemm<kNT, EpiBiasActHead<8>>(A, B, rows, p.out, p.in, 0, epi, s);
+                rc = launch_gemm<kNT, EpiBiasActHead<8>>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
             }
             if (rc) return rc;
             prof_mark(m, l, 0, 1, s);
@@ -1549,34 +1503,12 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
         }
         EpiBiasAct epi{p.H, p.ldh, m->params + p.b_off, p.act, quad_ok(p.H, p.ldh) && quad_ok(m->params + p.b_off, 4)};
         epi.drop = drop_cfg(m, l);
-        const bool affine_rows = A.rows.idx == nullptr && A.rows.half == 0;
-        const int64_t main_rows = (affine_rows && epi.drop.thr == 0u) ? tail_main_rows(rows, p.out) : 0;
-        if (!main_rows && for_backward && p.mask && act_mask_enabled()) {   // the dgrad of the next layer reads sign(H) instead of H
+        if (for_backward && p.mask && act_mask_enabled()) {   // the dgrad of the next layer reads sign(H) instead of H
             epi.mask = p.mask;
             p.mask_rows = rows;
         }
         prof_mark(m, l, 0, 0, s);
-        int rc;
-        if (main_rows) {
-            // tail rows as a launch of their own (the sign mask is tile-shape specific: not written).  On the same stream:
-            // a side stream with an event fork / join was measured at +20 us per step (cross-queue synchronisation costs
-            // more than the few microseconds of the tail launch it would hide); DCV_TAIL_AUX=1 keeps that form.
-            static const bool use_aux = [] { const char* e = getenv("DCV_TAIL_AUX"); return e && e[0] == '1'; }();
-            hipStream_t st = use_aux ? m->aux : s;
-            if (use_aux) {
-                rc = fork_aux(m, s);
-                if (rc) return rc;
-            }
-            EpiBiasAct et = epi;
-            et.C = epi.C + main_rows * epi.ldc;
-            rc = launch_gemm<kNT, EpiBiasAct>(rows_from(A, main_rows), B, rows - main_rows, p.out, p.in, 0, et, st);
-            if (rc) return rc;
-            rc = launch_gemm<kNT, EpiBiasAct>(A, B, main_rows, p.out, p.in, 0, epi, s);
-            if (rc) return rc;
-            if (use_aux) rc = join_aux(m, s);
-        } else {
-            rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s);
-        }
+        const int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
         if (rc) return rc;
         prof_mark(m, l, 0, 1, s);
     }
@@ -1852,7 +1784,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             eg.drop = drop_cfg(m, l - 1);
             eg.hscale = drop_hscale(m, l - 1);
             prof_mark(m, l, 2, 0, s);
-            rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks);
+            rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks, &m->tail);
             if (rc) return rc;
             prof_mark(m, l, 2, 1, s);
             float* tmp = dz_cur;

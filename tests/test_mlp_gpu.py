@@ -50,6 +50,12 @@ def rel_err(a, b):
     ([256, 128, 64, 4], 6000, 10, 2048, True),
     ([64, 32, 3], 3000, 5, 777, False),
     ([40, 5], 1000, 2, 500, True),
+    # the contract batch: 8192 pairs + lag = 8202 shared rows, one ragged row tile past a multiple of the
+    # CU count -- the products take the contraction-split tail tile (gemm.h: GemmDims::tail_split).  tanh layers: with a
+    # million leaky-ReLU units per batch a few pre-activations sit within float32 rounding of the kink, and one flipped
+    # slope (1 vs 0.01) moves a gradient entry by 1e-4 of the largest one -- in the float32 oracle just as in either
+    # arithmetic flavour of the engine (measured: FP32-input MFMA 3.8e-4, split 3e-7 on this very batch)
+    ([512, 256, 128, 3, "tanh"], 8300, 10, 8192, False),
 ])
 def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather, mode):
     """One Deep-TICA step (statistics, loss, every gradient) against a FLOAT64 run of the autograd oracle on the same
@@ -60,10 +66,13 @@ def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather, m
 
     from deep_cartograph_amd import hip
 
+    hidden_act = "leaky_relu"
+    if isinstance(dims[-1], str):
+        dims, hidden_act = dims[:-1], dims[-1]
     X = features[0] if dims[0] == 54 else ar_features(n, dims[0], 11)
     Xn, _, _ = normalized(X)
     P = Xn.shape[0] - lag
-    acts = ["leaky_relu"] * (len(dims) - 2) + [None]
+    acts = [hidden_act] * (len(dims) - 2) + [None]
     torch.manual_seed(3)
     ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
     ref64 = copy.deepcopy(ref).double()

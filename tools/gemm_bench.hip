@@ -91,8 +91,8 @@ int main(int argc, char** argv) {
     const int64_t R = argc > 1 ? atoll(argv[1]) : 131072;
     const int F = 512, H1 = 256, H2 = 128;
     float *X, *W1, *Hb, *dZ, *slab, *W2, *H2b, *bpart, *b1;
-    CK(hipMalloc(&X, (size_t)R * F * 4));
-    CK(hipMalloc(&W1, (size_t)H1 * F * 4));
+    CK(hipMalloc(&X, (size_t)R * (F + 64) * 4));
+    CK(hipMalloc(&W1, (size_t)H1 * (F + 64) * 4));
     CK(hipMalloc(&b1, (size_t)H1 * 4));
     CK(hipMalloc(&Hb, (size_t)R * H1 * 4));
     CK(hipMalloc(&dZ, (size_t)R * H1 * 4));
@@ -137,7 +137,10 @@ int main(int argc, char** argv) {
         return 0;
     }
     {   // L0 forward: [R,512] x [256,512]^T
-        Operand A = make_operand(X, F, F), B = make_operand(W1, F, F);
+        // DCV_LDPAD / DCV_LDPADW: floats added to the row pitch of X / W1 (<= 64): a 2 KiB pitch puts the 128-byte row
+        // segments of a stage on very few L2 channels
+        const int padx = getenv("DCV_LDPAD") ? atoi(getenv("DCV_LDPAD")) : 0, padw = getenv("DCV_LDPADW") ? atoi(getenv("DCV_LDPADW")) : 0;
+        Operand A = make_operand(X, F + padx, F), B = make_operand(W1, F + padw, F);
         EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};
         double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, it);
         printf("L0 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);

@@ -701,7 +701,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             }
         }
     }
-    auto read_frags = [&](Frags& f, const float* la, const float* lb, int g, bool sub = false) {
+    auto read_frags = [&](Frags& f, const float* la, const float* lb, int g) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             if constexpr (A_MM) {
@@ -709,10 +709,6 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) f.a[i][s] = frag_kmajor<TM>(la, wm + i * 32, g, s, lane);
-                if (sub) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) f.a[i][s] -= sha[i];
-                }
             }
         }
 #pragma unroll
@@ -724,12 +720,27 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) f.b[b][j][s] = frag_kmajor<TN>(lb + b * B_SZ, wn + j * 32, g, s, lane);
-                    if (sub) {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) f.b[b][j][s] -= shb[j];
-                    }
                 }
             }
+    };
+    // The column shift of a DMA-filled stage comes off the fragments right before their MFMA group -- one group after
+    // they were requested, so the subtraction never waits on LDS (applied inside read_frags it stalled every group on
+    // the reads it had just issued: covariance 110 -> 130 TFLOP/s at 5M x 256 together with two waves per SIMD).
+    auto sub_frags = [&](Frags& f) {
+        if constexpr (!A_MM) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) f.a[i][s] -= sha[i];
+        }
+        if constexpr (!B_MM) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) f.b[b][j][s] -= shb[j];
+        }
     };
     // Makes the 128-bit fragment registers opaque right before their MFMA group: the ds_read_b128 that
     // produced them must stay whole (hipcc otherwise scalarises a vector load whose lanes are consumed
@@ -1075,7 +1086,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             __syncthreads();   // last stage fully read before the buffers are reused
         } else {
         Frags f0, f1;
-        read_frags(f0, lds, lds + A_SZ, 0, dma_sub);
+        read_frags(f0, lds, lds + A_SZ, 0);
         int cur_buf = 0;
         for (int64_t st = 0; st < nst; ++st) {
             const float* la = lds + cur_buf * STAGE;
@@ -1083,15 +1094,17 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             const int nxt_buf = cur_buf + 1 == NBUF ? 0 : cur_buf + 1;
 #pragma unroll
             for (int g = 0; g < G; g += 2) {
-                read_frags(f1, la, lb, g + 1, dma_sub);
+                read_frags(f1, la, lb, g + 1);
                 __builtin_amdgcn_sched_barrier(0);
                 pin_frags(f0);
+                if (dma_sub) sub_frags(f0);
                 mfma_group(f0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 2 < G) {
-                    read_frags(f0, la, lb, g + 2, dma_sub);
+                    read_frags(f0, la, lb, g + 2);
                     __builtin_amdgcn_sched_barrier(0);
                     pin_frags(f1);
+                    if (dma_sub) sub_frags(f1);
                     mfma_group(f1);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {   // stage boundary, interleaved with the last group's MFMAs
@@ -1104,6 +1117,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     pin_frags(f1);
+                    if (dma_sub) sub_frags(f1);
                     mfma_step(f1, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef DCV_ABL_NOLOAD
@@ -1118,7 +1132,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_step(f1, 2);
                     __builtin_amdgcn_sched_barrier(0);
-                    read_frags(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0, dma_sub);
+                    read_frags(f0, lds + nxt_buf * STAGE, lds + nxt_buf * STAGE + A_SZ, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     mfma_step(f1, 3);
                     __builtin_amdgcn_sched_barrier(0);

@@ -298,7 +298,7 @@ inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reint
 // ------------------------------------------------------------------ kernels
 // grid.x = tiles_m * tiles_n (tile_n fastest), grid.z = k splits (TN only)
 template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
-__global__ __launch_bounds__(256) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
+__global__ __launch_bounds__(256, (NB == 2 ? 2 : 1)) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     // XCD-aware block -> (tile, split) map.  Blocks b and b + 8 are observed to share an XCD (and its
     // L2); the workgroups that read the same rows -- the column tiles of one row tile (NT / NN), the
@@ -418,7 +418,7 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
             // 256 CUs: two CUs would run two full-length workgroups on the same SIMDs, 1.4 x the launch time).
             const int64_t stages = K / Cfg::KB, ncu = num_cus();
             const int64_t all = (int64_t)d.tiles_m * d.tiles_n, regular = all - d.tiles_n;
-            if (tw && tw->ws && tail_split_enabled() && M % Cfg::TM != 0 && d.tiles_m >= 2 && K % Cfg::KB == 0 && stages >= 4 &&
+            if (tw && tw->ws && tail_split_enabled() && M % Cfg::TM != 0 && d.tiles_m >= 2 && K % Cfg::KB == 0 && stages >= 8 &&   // shorter contractions: measured slower
                 all <= 4 * ncu && cdiv(all, ncu) > cdiv(regular, ncu) && d.tiles_n <= tw->max_tiles_n) {
                 const int64_t want = stages / 2 < kTailMaxSplit ? stages / 2 : kTailMaxSplit;
                 const int64_t kc = cdiv(stages, want) * Cfg::KB;
@@ -565,7 +565,10 @@ template <int PL> using CfgPlBig = TileCfg<2, 2, 2, 2, PL == 3 ? DCV_PL3_BIG : 3
 #else
 template <int PL> using CfgPlBig = TileCfg<2, 2, 2, 2, PL == 3 ? 16 : 32, PL == 3 ? 3 : 2, true, PL>;
 #endif
-template <int PL> using CfgPlHalf = TileCfg<2, 2, 1, 2, 32, 2, true, PL>;
+#ifndef DCV_PLH_NBUF
+#define DCV_PLH_NBUF 2
+#endif
+template <int PL> using CfgPlHalf = TileCfg<2, 2, 1, 2, 32, DCV_PLH_NBUF, true, PL>;
 
 // NT product with plane operands: C[M,N] = A[M,K] . B[N,K]^T.  Returns DCV_EINVAL-free "not applicable" (1) when the
 // shape or the operands do not qualify -- the caller then takes the fp32-operand kernel -- and a DCV_E* (< 0) on error.

@@ -98,7 +98,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dZ, (size_t)R * H1 * 4));
     CK(hipMalloc(&W2, (size_t)H2 * H1 * 4));
     CK(hipMalloc(&H2b, (size_t)R * H2 * 4));
-    const int64_t slab_cap = (R + 255) / 256 + 1;   // slabs of H1 x F floats: one per smallest k-chunk (256 rows); launch_gemm refuses more splits than this
+    const int64_t slab_cap = (R + 127) / 128 + 1;   // slabs of H1 x F floats: one per smallest k-chunk (256 rows); launch_gemm refuses more splits than this
     CK(hipMalloc(&slab, (size_t)slab_cap * H1 * F * 4));
     CK(hipMalloc(&bpart, (size_t)(R / 32 + 8) * H1 * 4));
     std::vector<float> h((size_t)R * F);
@@ -127,11 +127,11 @@ int main(int argc, char** argv) {
             const int64_t splits = (P + kk - 1) / kk;
             float* cslab;
             CK(hipMalloc(&cslab, (size_t)splits * 2 * Fc * Fc * 4));
-            Operand op = make_operand(X, Fc, Fc);
+            Operand op = make_operand(X, Fc, Fc, identity_rows(), getenv("DCV_COV_NOSHIFT") ? nullptr : b1);   // column shift as in the product (dcv_lagged_cov)
             EpiSlab epi{cslab, Fc, Fc, 2, 0, true, splits};
             double ms = time_ms([&] { launch_gemm_cfg<kTN, CovCfg, 2, EpiSlab>(op, op, 10, Fc, Fc, P, kk, epi, s); }, it);
             printf("cov TN 2B kc=%5lld splits=%lld %8.1f us  %6.1f TF\n", (long long)kk, (long long)splits, ms * 1e3, 4.0 * P * Fc * Fc / ms / 1e9);
-            dump_stamps("cov", 1024);
+            dump_stamps("cov", 4);   // stamps are taken by the blockIdx.z == 0 workgroups: the four output tiles of the first contraction chunk
             CK(hipFree(cslab));
         }
         return 0;
@@ -155,7 +155,7 @@ int main(int argc, char** argv) {
     }
     {   // L0 wgrad: dZ[R,256]^T x X[R,512], split
         Operand A = make_operand(dZ, H1, H1), B = make_operand(X, F, F);
-        for (int64_t kc : (R < 32768 ? std::vector<int64_t>{256, 512, 1024} : std::vector<int64_t>{1024, 2048, 4096})) {
+        for (int64_t kc : (R < 32768 ? std::vector<int64_t>{128, 160, 192, 256, 288, 512, 1024} : std::vector<int64_t>{1024, 2048, 4096})) {
             EpiSlab epi{slab, H1, F, 1, 0, true, slab_cap};
             double ms = time_ms([&] { launch_gemm<kTN, EpiSlab>(A, B, H1, F, R, kc, epi, s); }, it);
             printf("L0 wgrad TN kc=%5lld %8.1f us  %6.1f TF\n", (long long)kc, ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);

@@ -298,7 +298,7 @@ inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reint
 // ------------------------------------------------------------------ kernels
 // grid.x = tiles_m * tiles_n (tile_n fastest), grid.z = k splits (TN only)
 template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
-__global__ __launch_bounds__(256, (NB == 2 ? 2 : 1)) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
     extern __shared__ __attribute__((aligned(16))) float lds_f[];
     // XCD-aware block -> (tile, split) map.  Blocks b and b + 8 are observed to share an XCD (and its
     // L2); the workgroups that read the same rows -- the column tiles of one row tile (NT / NN), the

@@ -14,6 +14,8 @@ kt_files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
 
 
 def short(name):
+    name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), true, 0>", r"Cfg\1\2\3\4k\5b\6s", name)   # trailing 0: no pre-split (plane) operands
+    name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), false, 0>", r"Cfg\1\2\3\4k\5b\6", name)
     name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), true>", r"Cfg\1\2\3\4k\5b\6s", name)    # s: split arithmetic
     name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), false>", r"Cfg\1\2\3\4k\5b\6", name)
     name = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d)>", r"Cfg\1\2\3\4k\5b\6", name)

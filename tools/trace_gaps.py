@@ -22,6 +22,8 @@ busy = sum(e - s for s, e, _ in win)
 gaps = sum(max(0, win[i + 1][0] - win[i][1]) for i in range(len(win) - 1))
 per = defaultdict(lambda: [0, 0])
 for s, e, n in win:
+    n = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), true, 0>", r"Cfg\1\2\3\4k\5b\6s", n)   # trailing 0: no pre-split (plane) operands
+    n = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), false, 0>", r"Cfg\1\2\3\4k\5b\6", n)
     n = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), true>", r"Cfg\1\2\3\4k\5b\6s", n)
     n = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d), false>", r"Cfg\1\2\3\4k\5b\6", n)
     n = re.sub(r"dcv::TileCfg<(\d), (\d), (\d), (\d), (\d+), (\d)>", r"Cfg\1\2\3\4k\5b\6", n)

@@ -18,6 +18,7 @@ struct CovPlan {
     size_t stats_ws;  // bytes of the column-statistics workspace
     size_t sums;      // bytes of the three [4][F] float64 blocks
     size_t slab;      // bytes of the split-K slabs
+    size_t asum;      // bytes of the per-chunk column sums of z_t ([splits][F] floats; used when a shift is given)
 };
 
 static CovPlan cov_plan(int64_t n_pairs, int F, int lag) {
@@ -39,6 +40,7 @@ static CovPlan cov_plan(int64_t n_pairs, int F, int lag) {
     p.stats_ws = align_up(dcv_col_stats_workspace(n_pairs, F), 256);
     p.sums = align_up((size_t)3 * 4 * F * sizeof(double), 256);
     p.slab = align_up((size_t)p.splits * per_split, 256);
+    p.asum = align_up((size_t)p.splits * F * sizeof(float), 256);
     return p;
 }
 
@@ -75,6 +77,24 @@ __global__ void cov_sums_kernel(const double* __restrict__ s_all, const double* 
     b[f] = lag > 0 ? (st - s_head[f] + s_tail[f] - sh) : 0.0;
 }
 
+// The same two sums from the covariance kernel's own per-chunk column sums of z_t = x_t - shift (float32 inside a chunk
+// of <= 2048 centred values, float64 across chunks, chunk order): a = sum_z asum[z] ; b = a - head + tail, where head /
+// tail are the sums of the raw `lag` first / last rows (the shift cancels).  Saves the pass over the matrix.
+__global__ void cov_sums_fused_kernel(const float* __restrict__ asum, int64_t splits, const double* __restrict__ s_head,
+                                      const double* __restrict__ s_tail, int F, int lag, double* __restrict__ a,
+                                      double* __restrict__ b) {
+    const int f = blockIdx.x;   // one wave per column: lanes over the chunks, fixed-order combine
+    const int lane = threadIdx.x;
+    double acc = 0.0;
+    for (int64_t z = lane; z < splits; z += 64) acc += (double)asum[z * F + f];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) {
+        a[f] = acc;
+        b[f] = lag > 0 ? (acc - s_head[f] + s_tail[f]) : 0.0;
+    }
+}
+
 }  // namespace dcv
 
 using namespace dcv;
@@ -82,7 +102,7 @@ using namespace dcv;
 extern "C" size_t dcv_lagged_cov_workspace(int64_t n_pairs, int32_t F, int32_t lag) {
     if (n_pairs <= 0 || F <= 0 || lag < 0) return 0;
     const CovPlan p = cov_plan(n_pairs, F, lag);
-    return p.stats_ws + p.sums + p.slab;
+    return p.stats_ws + p.sums + p.slab + p.asum;
 }
 
 extern "C" int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int64_t ld, int32_t lag,
@@ -100,18 +120,28 @@ extern "C" int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int6
     double* A = out_d + 2 * (int64_t)F;
     double* B = A + (int64_t)F * F;
 
-    // column sums of x_t, and of the `lag` head / tail rows that turn them into the x_lag sums
-    int rc = dcv_col_stats(X_d, n_pairs, F, ld, sums, stats_ws, p.stats_ws, stream);
-    if (rc) return rc;
-    if (lag > 0) {
+    float* asum = reinterpret_cast<float*>(ws + p.stats_ws + p.sums + p.slab);
+    // With a shift (the standardised / centred case) the column sums of z_t fall out of the covariance kernel itself;
+    // without one the values are not centred and a float32 chunk sum would cost digits: the float64 statistics pass stays.
+    static const bool fuse_off = [] { const char* e = getenv("DCV_COV_FUSED_SUMS"); return e && e[0] == '0'; }();
+    const bool fused_sums = shift_d != nullptr && !fuse_off;
+    int rc = DCV_OK;
+    if (!fused_sums) {
+        // column sums of x_t over all pairs
+        rc = dcv_col_stats(X_d, n_pairs, F, ld, sums, stats_ws, p.stats_ws, stream);
+        if (rc) return rc;
+    }
+    if (lag > 0) {   // the `lag` head / tail rows that turn the x_t sums into the x_lag sums
         rc = dcv_col_stats(X_d, lag, F, ld, sums + 4 * F, stats_ws, p.stats_ws, stream);
         if (rc) return rc;
         rc = dcv_col_stats(X_d + n_pairs * ld, lag, F, ld, sums + 8 * F, stats_ws, p.stats_ws, stream);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(cov_sums_kernel, dim3((F + 255) / 256), dim3(256), 0, s, sums, sums + 4 * F, sums + 8 * F, shift_d,
-                       n_pairs, F, lag, a, b);
-    DCV_CHECK_LAUNCH();
+    if (!fused_sums) {
+        hipLaunchKernelGGL(cov_sums_kernel, dim3((F + 255) / 256), dim3(256), 0, s, sums, sums + 4 * F, sums + 8 * F, shift_d,
+                           n_pairs, F, lag, a, b);
+        DCV_CHECK_LAUNCH();
+    }
 
     // Always the FP32-input MFMA, whatever dcv_set_gemm_mode says: a covariance is a sum of thousands of same-sign
     // products per accumulator and the BF16 matrix pipe adds into its accumulator by truncation -- measured bias
@@ -119,11 +149,23 @@ extern "C" int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int6
     // held to 1e-5.
     const Operand op = make_operand(X_d, ld, F, identity_rows(), shift_d);
     EpiSlab epi{slab, F, F, p.nb, 0, quad_ok(slab, F), p.splits};   // p.splits slabs are what cov_plan sized the workspace for
-    if (p.nb == 2)
-        rc = launch_gemm_cfg<kTN, CfgCovT<false>, 2, EpiSlab>(op, op, lag, F, F, n_pairs, p.k_chunk, epi, s);
-    else
-        rc = launch_gemm_cfg<kTN, CfgBigT<false>, 1, EpiSlab>(op, op, 0, F, F, n_pairs, p.k_chunk, epi, s);
-    if (rc) return rc;
+    if (fused_sums) {
+        EpiSlabSum es{epi, asum};
+        if (p.nb == 2)
+            rc = launch_gemm_cfg<kTN, CfgCovT<false>, 2, EpiSlabSum>(op, op, lag, F, F, n_pairs, p.k_chunk, es, s);
+        else
+            rc = launch_gemm_cfg<kTN, CfgBigT<false>, 1, EpiSlabSum>(op, op, 0, F, F, n_pairs, p.k_chunk, es, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cov_sums_fused_kernel, dim3(F), dim3(64), 0, s, (const float*)asum, p.splits, (const double*)(sums + 4 * F),
+                           (const double*)(sums + 8 * F), F, lag, a, b);
+        DCV_CHECK_LAUNCH();
+    } else {
+        if (p.nb == 2)
+            rc = launch_gemm_cfg<kTN, CfgCovT<false>, 2, EpiSlab>(op, op, lag, F, F, n_pairs, p.k_chunk, epi, s);
+        else
+            rc = launch_gemm_cfg<kTN, CfgBigT<false>, 1, EpiSlab>(op, op, 0, F, F, n_pairs, p.k_chunk, epi, s);
+        if (rc) return rc;
+    }
     const int64_t FF = (int64_t)F * F;
     hipLaunchKernelGGL(cov_reduce_kernel, dim3((unsigned)cdiv(FF, 256)), dim3(256), 0, s, slab, p.splits, p.nb, FF, A, B);
     DCV_CHECK_LAUNCH();

@@ -24,6 +24,7 @@
 // bases, ld % 4 == 0 and inner extents that are multiples of 4, otherwise the scalar loaders
 // are used.
 #pragma once
+#include <type_traits>
 #include "common.h"
 
 namespace dcv {
@@ -76,6 +77,10 @@ __device__ __forceinline__ void split3(const float (&x)[8], u32x4& p1, u32x4& p2
 __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4& v) { return __builtin_bit_cast(bf16x8, v); }
 
 enum GemmMode { kNT = 0, kNN = 1, kTN = 2 };
+
+// epilogues that also want the column sums of the (shifted) A operand of a TN product declare `kASum = true`
+template <class E, class = void> struct epi_has_asum : std::false_type {};
+template <class E> struct epi_has_asum<E, std::void_t<decltype(E::kASum)>> : std::bool_constant<E::kASum> {};
 
 // Logical row -> row of the underlying matrix.  Batch matrices of the MLP engine are never
 // materialised: logical row r < half is sample r (x_t), r >= half is sample r-half shifted by
@@ -867,6 +872,19 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         split_frags(f, p);
         mfma_planes(p, [](int) {});
     };
+    // Column sums of the A operand as the MFMAs see it (TN products, FP32-input flavour): a lane owns one column of each
+    // of its A fragments, so summing the fragment values it feeds to the matrix pipe gives sum_k A[k][m] for free -- the
+    // covariance's sum of z_t without a pass of its own over the matrix (4 vector adds per fragment against 16-32 MFMAs).
+    constexpr bool kASum = epi_has_asum<Epi>::value && MODE == kTN && !Cfg::SPLIT;
+    float asum[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) asum[i] = 0.f;
+    auto add_asum = [&](const Frags& f) {
+        if constexpr (kASum) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) asum[i] += (f.a[i][0] + f.a[i][1]) + (f.a[i][2] + f.a[i][3]);
+        }
+    };
     auto mfma_step = [&](const Frags& f, int s) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -914,9 +932,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
         for (int g = 0; g < G; g += 2) {
             if (g + 1 < G) read_frags(f1, la, lb, g + 1);
+            add_asum(f0);
             mfma_group(f0);
             if (g + 1 < G) {
                 if (g + 2 < G) read_frags(f0, la, lb, g + 2);
+                add_asum(f1);
                 mfma_group(f1);
             }
         }
@@ -925,6 +945,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         for (int g = 0; g < G; ++g) {
             Frags f0;
             read_frags(f0, la, lb, g);
+            add_asum(f0);
             mfma_group(f0);
         }
 #endif
@@ -1098,6 +1119,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 __builtin_amdgcn_sched_barrier(0);
                 pin_frags(f0);
                 if (dma_sub) sub_frags(f0);
+                add_asum(f0);
                 mfma_group(f0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (g + 2 < G) {
@@ -1105,6 +1127,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                     __builtin_amdgcn_sched_barrier(0);
                     pin_frags(f1);
                     if (dma_sub) sub_frags(f1);
+                    add_asum(f1);
                     mfma_group(f1);
                     __builtin_amdgcn_sched_barrier(0);
                 } else {   // stage boundary, interleaved with the last group's MFMAs
@@ -1118,6 +1141,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                     __builtin_amdgcn_sched_barrier(0);
                     pin_frags(f1);
                     if (dma_sub) sub_frags(f1);
+                    add_asum(f1);
                     mfma_step(f1, 0);
                     __builtin_amdgcn_sched_barrier(0);
 #ifndef DCV_ABL_NOLOAD
@@ -1370,6 +1394,17 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                         if (row < d.M && col < d.N) epi.one(b, row, col, acc[b][i][j][e]);
                     }
                 }
+    }
+    if constexpr (kASum) {
+        // one copy per (row tile of C = column block of A, contraction chunk): the first column tile's waves of column 0
+        if (epi.asum != nullptr && tile_n == 0 && (wave % Cfg::WAVES_N) == 0) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const float v = asum[i] + __shfl_xor(asum[i], 32, 64);   // the two k-halves of the lanes
+                const int64_t m = m0 + wm + i * 32 + (lane & 31);
+                if (lane < 32 && m < d.M) epi.asum[epi.z * epi.M + m] = v;
+            }
+        }
     }
 }
 

@@ -293,6 +293,12 @@ struct EpiSlab {  // split-K partials: slab[z][which][M][N]
     }
 };
 
+// EpiSlab + the column sums of the A operand per contraction chunk: asum[z][M] (gemm.h: kASum)
+struct EpiSlabSum : EpiSlab {
+    static constexpr bool kASum = true;
+    float* asum = nullptr;
+};
+
 inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
 
 // ------------------------------------------------------------------ kernels
@@ -321,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(Operand A, Operand B, int6
         tile_n = tile - tile_m * d.tiles_n;
         k_begin = (int64_t)split * d.k_chunk;
         k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
-        if constexpr (std::is_same<Epi, EpiSlab>::value) epi.z = split;
+        if constexpr (std::is_base_of<EpiSlab, Epi>::value) epi.z = split;
     } else {
         int tile = blockIdx.x;
         const int regular = d.tail_split > 0 ? (d.tiles_m - 1) * d.tiles_n : d.tiles_m * d.tiles_n;
@@ -438,7 +444,7 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
     DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
                 (long long)tiles, (long long)splits);
     DCV_REQUIRE(!(Cfg::SPLIT && (A.shift || B.shift)), "gemm: a column shift needs the FP32-input MFMA flavour");
-    if constexpr (std::is_same<Epi, EpiSlab>::value) {
+    if constexpr (std::is_base_of<EpiSlab, Epi>::value) {
         // every split writes its own slab: refuse the launch instead of writing past the caller's buffer
         if (splits > epi.cap) {
             set_error("gemm: %lld split-K slabs needed, the slab buffer holds %lld", (long long)splits, (long long)epi.cap);

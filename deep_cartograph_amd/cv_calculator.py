@@ -477,7 +477,9 @@ class LinearCalculator(CVCalculator):
         # z = xn - shift with shift ~ column mean of xn keeps the fp32 products well conditioned
         shift = (self.features_stats["mean"].astype(np.float64) - np.asarray(self.features_norm_mean, dtype=np.float64)) / \
             np.asarray(self.features_norm_range, dtype=np.float64)
-        shift_t = _dev(shift.astype(np.float32), dev) if np.any(np.abs(shift) > 1e-3) else None
+        # always passed, even when the standardisation already centred the columns (shift ~ 0): with a shift the kernel
+        # knows its operand is centred and takes the column sums of z_t from its own fragments (cov.hip), no extra pass
+        shift_t = _dev(shift.astype(np.float32), dev)
         Xh, n_pairs_local = append_halo(X, lag, self.comm)
         if n_pairs_local <= 0:
             raise ValueError("not enough frames for the requested lag time")

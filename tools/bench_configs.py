@@ -43,11 +43,13 @@ def c3(n=5_000_000, F=256, lag=10):
     t_norm = timed(lambda: hip.normalize(X, m, r, out=X), reps=1)
     out["normalize_GBps"] = 8.0 * n * F / t_norm / 1e9
     P = n - lag
-    t_cov = timed(lambda: hip.lagged_cov_raw(X, P, lag))
+    shift = hip.finalize_stats(hip.col_stats_raw(X), n)["mean"]   # ~0 after the standardisation above; the calculators always pass it
+    shift = torch.from_numpy(np.asarray(shift, dtype=np.float32)).cuda()
+    t_cov = timed(lambda: hip.lagged_cov_raw(X, P, lag, shift))
     out["lagged_cov_ms"] = t_cov * 1e3
     out["lagged_cov_TFLOPs"] = 4.0 * P * F * F / t_cov / 1e12
     out["lagged_cov_frac_of_157.3"] = out["lagged_cov_TFLOPs"] / 157.3
-    t_pca = timed(lambda: hip.lagged_cov_raw(X, n, 0))
+    t_pca = timed(lambda: hip.lagged_cov_raw(X, n, 0, shift))
     out["pca_cov_TFLOPs"] = 2.0 * n * F * F / t_pca / 1e12
     W = torch.randn(F, 2, device="cuda") / 16
     t_proj = timed(lambda: hip.project_linear(X, W, want_minmax=True))

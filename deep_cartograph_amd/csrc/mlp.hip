@@ -108,8 +108,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ Z
     for (int c0 = 0; c0 < n; c0 += cols) {
         const int c = c0 + c_in;
         float s = 0.f;
-        if (g < groups && c < n)
-            for (int64_t r = r0 + g; r < r1; r += groups) s += Z[r * ld + c];
+        if (g < groups && c < n) {
+            // eight loads in flight, added in row order (the same sum as a serial walk, without its dependent round trips)
+            for (int64_t rb = r0 + g; rb < r1; rb += 8 * (int64_t)groups) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int64_t r = rb + (int64_t)u * groups;
+                    v[u] = r < r1 ? Z[r * ld + c] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s += v[u];
+            }
+        }
         red[t] = s;
         __syncthreads();
         if (g == 0 && c < n) {
@@ -993,21 +1004,37 @@ static head_backward_fn_t head_backward_fn(int d) {
 
 // ------------------------------------------------------------------ autoencoder loss
 // SSE = sum ((y - xn) * range)^2 over rows x F ; part[block]
+// `ticket` != null: the last block to finish adds the partials up in block order (the sum sum_partials_kernel would
+// produce) into out[0] and, when `log` != null, appends the step's loss record (ae_log_kernel) -- the one-GPU step
+// then needs neither of those two launches.
 __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y, int64_t ldy, const float* __restrict__ Xn,
                                                      int64_t ldx, RowMap rows, int64_t R, int F,
-                                                     const float* __restrict__ range, double* __restrict__ part) {
+                                                     const float* __restrict__ range, double* __restrict__ part,
+                                                     unsigned* __restrict__ ticket, double* __restrict__ out, double Bg,
+                                                     double* __restrict__ log, int* __restrict__ log_count, int log_cap,
+                                                     int log_width) {
     __shared__ double red[256];
     const int t = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * kSseRows;
     const int64_t r1 = r0 + kSseRows < R ? r0 + kSseRows : R;
+    // the block's kSseRows x F elements flat over the threads, four independent element loads in flight per thread
+    // (a thread that walked its rows one after the other spent the kernel waiting: 16 dependent round trips, 27 us)
     double s = 0.0;
-    for (int64_t r = r0; r < r1; ++r) {
-        const float* y = Y + r * ldy;
-        const float* x = Xn + rows.template get<true>(r) * ldx;
-        for (int c = t; c < F; c += 256) {
-            const float e = (y[c] - x[c]) * range[c];
-            s += (double)e * (double)e;
+    const int per_block = (int)(r1 - r0) * F;
+    for (int e0 = t; e0 < per_block; e0 += 4 * 256) {
+        float ev[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + 256 * u;
+            ev[u] = 0.f;
+            if (e < per_block) {
+                const int rr = e / F, c = e - rr * F;
+                const int64_t r = r0 + rr;
+                ev[u] = (Y[r * ldy + c] - Xn[rows.template get<true>(r) * ldx + c]) * range[c];
+            }
         }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s += (double)ev[u] * (double)ev[u];
     }
     red[t] = s;
     __syncthreads();
@@ -1016,6 +1043,33 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
         __syncthreads();
     }
     if (t == 0) part[blockIdx.x] = red[0];
+    if (ticket == nullptr) return;
+    __shared__ int is_last;
+    __threadfence();
+    if (t == 0) {
+        const unsigned prev = atomicAdd(ticket, 1u);
+        is_last = prev == gridDim.x - 1;
+        if (is_last) *ticket = 0u;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    if (t < 64) {   // one wave, the arithmetic of sum_partials_kernel: lanes over the blocks, shuffle tree
+        double tot = 0.0;
+        for (int b = t; b < (int)gridDim.x; b += 64) tot += __builtin_nontemporal_load(part + b);
+        for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+        if (t == 0) {
+            out[0] = tot;
+            if (log != nullptr) {
+                const int slot = *log_count;
+                if (slot < log_cap) {
+                    log[(int64_t)slot * log_width + 0] = tot / (Bg * (double)F);
+                    log[(int64_t)slot * log_width + 1] = Bg;
+                }
+                *log_count = slot + 1;
+            }
+        }
+    }
 }
 
 // dY = scale * (y - xn) * range^2 * act'(y)
@@ -1612,10 +1666,19 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
         DCV_CHECK_LAUNCH();
     } else {
         const int nb = (int)cdiv(R, kSseRows);
-        hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart);
-        DCV_CHECK_LAUNCH();
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, m->spart, nb, 1, m->stats);
-        DCV_CHECK_LAUNCH();
+        if (fuse_head) {   // one-GPU step: final sum and loss record in the last block of the same launch
+            DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
+            hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
+                               m->ticket, m->stats, (double)batch, m->log, m->log_count, m->log_cap, m->log_width);
+            DCV_CHECK_LAUNCH();
+            m->head_done = true;
+        } else {
+            hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
+                               (unsigned*)nullptr, (double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, 0, 0);
+            DCV_CHECK_LAUNCH();
+            hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, m->spart, nb, 1, m->stats);
+            DCV_CHECK_LAUNCH();
+        }
     }
     m->last_batch = batch;
     return DCV_OK;
@@ -1686,8 +1749,11 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         }
     } else {
         const int F = m->desc.dims[0];
-        hipLaunchKernelGGL(ae_log_kernel, dim3(1), dim3(64), 0, s, m->stats, (double)global_batch, F, m->log, m->log_count, m->log_cap, m->log_width);
-        DCV_CHECK_LAUNCH();
+        if (!m->head_done) {
+            hipLaunchKernelGGL(ae_log_kernel, dim3(1), dim3(64), 0, s, m->stats, (double)global_batch, F, m->log, m->log_count, m->log_cap, m->log_width);
+            DCV_CHECK_LAUNCH();
+        }
+        m->head_done = false;
         if (!train) return DCV_OK;
         const float scale = (float)(2.0 / ((double)global_batch * (double)F));
         int64_t blocks = cdiv(R * F, 256);

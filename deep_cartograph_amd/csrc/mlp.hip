@@ -795,7 +795,7 @@ static tica_stats_fn_t tica_stats_rows_fn(int d) {
     }
 }
 // rows per block of the kernel above: at most 512 blocks, whole multiples of 256 rows
-static int stats_rows_per_block(int64_t batch) { return (int)(cdiv(cdiv(batch, 512), 256) * 256); }
+static int stats_rows_per_block(int64_t batch) { return (int)(cdiv(cdiv(batch, 256), 256) * 256); }   // <= 256 blocks: each ends on one ticket (~70 ns apiece, serialised)
 
 // Gradient of the loss w.r.t. the network outputs.  Sample i (0 <= i < B) has f_t in row i and f_lag in
 // row i + lag_off:  dL/df_t[i] = Gu u_i + Gv v_i + c,  dL/df_lag[i] = Gv u_i  (u = f_t - mu, v = f_lag - mu).
@@ -1012,11 +1012,11 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
                                                      const float* __restrict__ range, double* __restrict__ part,
                                                      unsigned* __restrict__ ticket, double* __restrict__ out, double Bg,
                                                      double* __restrict__ log, int* __restrict__ log_count, int log_cap,
-                                                     int log_width) {
+                                                     int log_width, int rows_per_block) {
     __shared__ double red[256];
     const int t = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * kSseRows;
-    const int64_t r1 = r0 + kSseRows < R ? r0 + kSseRows : R;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
     // the block's kSseRows x F elements flat over the threads, four independent element loads in flight per thread
     // (a thread that walked its rows one after the other spent the kernel waiting: 16 dependent round trips, 27 us)
     double s = 0.0;
@@ -1665,16 +1665,23 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
         hipLaunchKernelGGL(sum_partials_kernel, dim3(m->stats_len), dim3(64), 0, s, m->spart, nb, m->stats_len, m->stats);
         DCV_CHECK_LAUNCH();
     } else {
-        const int nb = (int)cdiv(R, kSseRows);
+        // about 32 elements per thread, at most 512 blocks: every block ends on one ticket (an atomic on one address costs
+        // ~70 ns and they serialise: 1024 blocks measured 81 us for a 2 MB pass), never fewer than kSseRows rows per block
+        int64_t want = cdiv(R * (int64_t)m->desc.dims[0], 256 * 32);
+        if (want > 512) want = 512;
+        if (want < 1) want = 1;
+        int64_t rpb = cdiv(R, want);
+        if (rpb < kSseRows) rpb = kSseRows;
+        const int nb = (int)cdiv(R, rpb);
         if (fuse_head) {   // one-GPU step: final sum and loss record in the last block of the same launch
             DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
             hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
-                               m->ticket, m->stats, (double)batch, m->log, m->log_count, m->log_cap, m->log_width);
+                               m->ticket, m->stats, (double)batch, m->log, m->log_count, m->log_cap, m->log_width, (int)rpb);
             DCV_CHECK_LAUNCH();
             m->head_done = true;
         } else {
             hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
-                               (unsigned*)nullptr, (double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, 0, 0);
+                               (unsigned*)nullptr, (double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, 0, 0, (int)rpb);
             DCV_CHECK_LAUNCH();
             hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, m->spart, nb, 1, m->stats);
             DCV_CHECK_LAUNCH();

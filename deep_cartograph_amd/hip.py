@@ -6,6 +6,7 @@ otherwise -- there is no CPU path.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -493,11 +494,22 @@ class Mlp:
         if not train:
             self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=False)
             return
-        pending = []
+        rows = int(batch if batch is not None else idx.numel())
+        env = os.environ.get("DCV_DP_OVERLAP")
+        # The two-piece form pays one more collective launch (~15-20 us of latency at these message sizes) to hide the
+        # upper layers' all-reduce under the layer-0 weight gradient: worth it only when that product outlasts a
+        # collective -- not at a few thousand rows per rank (8192-pair global batch over 1-8 ranks), where the whole
+        # gradient buffer goes out as one all-reduce.
+        overlap = (rows >= 32768) if env is None else env == "1"
         upper, lower = self.upper_grads_view(), self.layer0_grads_view()
+        if not overlap or not upper.numel():
+            self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=True)
+            dist.all_reduce(self.grads_view(), op=dist.ReduceOp.SUM, group=group)
+            self.apply()
+            return
+        pending = []
         self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=True,
-                      on_upper_grads=(lambda: pending.append(dist.all_reduce(upper, op=dist.ReduceOp.SUM, group=group, async_op=True)))
-                      if upper.numel() else None)
+                      on_upper_grads=lambda: pending.append(dist.all_reduce(upper, op=dist.ReduceOp.SUM, group=group, async_op=True)))
         dist.all_reduce(lower, op=dist.ReduceOp.SUM, group=group)
         for w in pending:
             w.wait()

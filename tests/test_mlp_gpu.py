@@ -129,6 +129,36 @@ def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather, m
     print(f"{mode} {dims} batch {batch}: worst gradient deviation from float64 = {worst:.2e} of the largest entry")
 
 
+def test_contract_batch_step_is_reproducible():
+    """The contraction-split tail tile (8202 rows: 512 regular + 32 tail-chunk workgroups per product) adds its chunks up in
+    chunk order whatever the arrival order: statistics, loss and every gradient of repeated steps on the same weights are
+    bit-identical, in two engines and across repetitions."""
+    from deep_cartograph_amd import hip
+
+    dims, lag, batch = [512, 256, 128, 3], 10, 8192
+    acts = ["leaky_relu", "leaky_relu", None]
+    Xn, _, _ = normalized(ar_features(8300, dims[0], 21))
+    torch.manual_seed(4)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    Xd = torch.from_numpy(Xn).cuda()
+    seen = []
+    for _ in range(2):
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+        push_params(eng, linears_of(ref.nn))
+        eng.reset_log(8)
+        for _rep in range(3):
+            eng.forward(Xd, row0=5, batch=batch)
+            stats = eng.stats_view().cpu().numpy().copy()
+            eng.backward(Xd, row0=5, batch=batch)
+            seen.append((stats, eng.grads_view().cpu().numpy().copy()))
+        log = eng.read_log()
+        assert np.all(log[:, 0] == log[0, 0])
+        eng.close()
+    for st, g in seen[1:]:
+        np.testing.assert_array_equal(st, seen[0][0])
+        np.testing.assert_array_equal(g, seen[0][1])
+
+
 def test_deeptica_row_sharing_equivalence():
     """Contiguous batches evaluate the network once on the batch + lag rows both halves share; the
     result must equal the two-halves evaluation (same rows through the same weights)."""

@@ -394,7 +394,13 @@ struct TailWs {
     int64_t cap = 0;
     int max_tiles_n = 0;
 };
-constexpr int kTailMaxSplit = 8;
+#ifndef DCV_TAIL_MAXSPLIT
+#define DCV_TAIL_MAXSPLIT 4   // measured at 8202 x 256 x 512: 2 chunks 26.5 us, 3: 25.8, 4: 25.5, 6: 25.4, 8: 26-28, 16: 34
+#endif
+constexpr int kTailMaxSplit = DCV_TAIL_MAXSPLIT;
+#ifndef DCV_TAIL_MINSTAGES
+#define DCV_TAIL_MINSTAGES 2   // stages per tail chunk
+#endif
 inline bool tail_split_enabled() {
     static const bool on = [] { const char* e = getenv("DCV_TAIL_KSPLIT"); return !(e && e[0] == '0'); }();
     return on;
@@ -426,7 +432,7 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
             const int64_t all = (int64_t)d.tiles_m * d.tiles_n, regular = all - d.tiles_n;
             if (tw && tw->ws && tail_split_enabled() && M % Cfg::TM != 0 && d.tiles_m >= 2 && K % Cfg::KB == 0 && stages >= 8 &&   // shorter contractions: measured slower
                 all <= 4 * ncu && cdiv(all, ncu) > cdiv(regular, ncu) && d.tiles_n <= tw->max_tiles_n) {
-                const int64_t want = stages / 2 < kTailMaxSplit ? stages / 2 : kTailMaxSplit;
+                const int64_t want = stages / DCV_TAIL_MINSTAGES < kTailMaxSplit ? stages / DCV_TAIL_MINSTAGES : kTailMaxSplit;
                 const int64_t kc = cdiv(stages, want) * Cfg::KB;
                 const int64_t S = cdiv(K, kc);
                 if (S >= 2 && (int64_t)d.tiles_n * S * Cfg::FM * Cfg::FN * 16 * 256 <= tw->cap) {

@@ -398,6 +398,9 @@ struct TailWs {
 #define DCV_TAIL_MAXSPLIT 4   // measured at 8202 x 256 x 512: 2 chunks 26.5 us, 3: 25.8, 4: 25.5, 6: 25.4, 8: 26-28, 16: 34
 #endif
 constexpr int kTailMaxSplit = DCV_TAIL_MAXSPLIT;
+#ifndef DCV_TAIL_STAGES_MIN
+#define DCV_TAIL_STAGES_MIN 8   // contraction stages below which the tail tile stays whole
+#endif
 #ifndef DCV_TAIL_MINSTAGES
 #define DCV_TAIL_MINSTAGES 2   // stages per tail chunk
 #endif
@@ -430,7 +433,7 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
             // 256 CUs: two CUs would run two full-length workgroups on the same SIMDs, 1.4 x the launch time).
             const int64_t stages = K / Cfg::KB, ncu = num_cus();
             const int64_t all = (int64_t)d.tiles_m * d.tiles_n, regular = all - d.tiles_n;
-            if (tw && tw->ws && tail_split_enabled() && M % Cfg::TM != 0 && d.tiles_m >= 2 && K % Cfg::KB == 0 && stages >= 8 &&   // shorter contractions: measured slower
+            if (tw && tw->ws && tail_split_enabled() && M % Cfg::TM != 0 && d.tiles_m >= 2 && K % Cfg::KB == 0 && stages >= DCV_TAIL_STAGES_MIN &&   // shorter contractions: measured slower
                 all <= 4 * ncu && cdiv(all, ncu) > cdiv(regular, ncu) && d.tiles_n <= tw->max_tiles_n) {
                 const int64_t want = stages / DCV_TAIL_MINSTAGES < kTailMaxSplit ? stages / DCV_TAIL_MINSTAGES : kTailMaxSplit;
                 const int64_t kc = cdiv(stages, want) * Cfg::KB;

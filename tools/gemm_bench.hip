@@ -112,6 +112,13 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(H2b, h.data(), (size_t)R * H2 * 4, hipMemcpyHostToDevice));
     CK(hipMemset(Hb, 0, (size_t)R * H1 * 4));
     hipStream_t s = 0;
+    TailWs tw;   // workspace of the contraction-split tail tile, as the engine owns one (DCV_BENCH_NOTAIL=1: none)
+    tw.cap = 8ll * 16 * 64 * 256;
+    tw.max_tiles_n = 8;
+    CK(hipMalloc(&tw.ws, (size_t)tw.cap * 4));
+    CK(hipMalloc(&tw.cnt, 8 * sizeof(unsigned)));
+    CK(hipMemset(tw.cnt, 0, 8 * sizeof(unsigned)));
+    const TailWs* twp = getenv("DCV_BENCH_NOTAIL") ? nullptr : &tw;
     const int it = argc > 2 ? atoi(argv[2]) : 20;
     if (argc > 3 && !strcmp(argv[3], "cov")) {   // lagged covariance: X[R,256]^T x (X, X shifted by 10 rows), two B operands
         const int Fc = 256;
@@ -142,11 +149,11 @@ int main(int argc, char** argv) {
         const int padx = getenv("DCV_LDPAD") ? atoi(getenv("DCV_LDPAD")) : 0, padw = getenv("DCV_LDPADW") ? atoi(getenv("DCV_LDPADW")) : 0;
         Operand A = make_operand(X, F + padx, F), B = make_operand(W1, F + padw, F);
         EpiBiasAct epi{Hb, H1, b1, DCV_ACT_LEAKY_RELU, true};
-        double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, it);
+        double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s, nullptr, twp); }, it);
         printf("L0 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H1 * F / ms / 1e9);
-        double ms1 = time_ms_single([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s); }, 20);
+        double ms1 = time_ms_single([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s, nullptr, twp); }, 20);
         auto t0 = std::chrono::high_resolution_clock::now();
-        for (int i = 0; i < 200; ++i) launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s);
+        for (int i = 0; i < 200; ++i) launch_gemm<kNT, EpiBiasAct>(A, B, R, H1, F, 0, epi, s, nullptr, twp);
         auto t1 = std::chrono::high_resolution_clock::now();
         CK(hipDeviceSynchronize());
         printf("L0 fwd   single launch between events %8.1f us ; host time per enqueue (200 back-to-back) %6.1f us\n", ms1 * 1e3,
@@ -164,14 +171,14 @@ int main(int argc, char** argv) {
     {   // L1 forward: [R,256] x [128,256]^T
         Operand A = make_operand(Hb, H1, H1), B = make_operand(W2, H1, H1);
         EpiBiasAct epi{H2b, H2, b1, DCV_ACT_LEAKY_RELU, true};
-        double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H2, H1, 0, epi, s); }, it);
+        double ms = time_ms([&] { launch_gemm<kNT, EpiBiasAct>(A, B, R, H2, H1, 0, epi, s, nullptr, twp); }, it);
         printf("L1 fwd   NT %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H2 * H1 / ms / 1e9);
         dump_stamps("L1 fwd", (int)(R / 128));
     }
     {   // L1 dgrad: dZ2[R,128] x W2[128,256]
         Operand A = make_operand(H2b, H2, H2), B = make_operand(W2, H1, H1);
         EpiActGrad epi{dZ, H1, Hb, H1, DCV_ACT_LEAKY_RELU, bpart, H1, true};
-        double ms = time_ms([&] { launch_gemm<kNN, EpiActGrad>(A, B, R, H1, H2, 0, epi, s); }, it);
+        double ms = time_ms([&] { launch_gemm<kNN, EpiActGrad>(A, B, R, H1, H2, 0, epi, s, nullptr, twp); }, it);
         printf("L1 dgrad NN %8.1f us  %6.1f TF\n", ms * 1e3, 2.0 * R * H2 * H1 / ms / 1e9);
         dump_stamps("L1 dgrad", (int)(R / 128 * 2));
     }

@@ -1637,7 +1637,7 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
     hipStream_t s = as_stream(stream);
     const RowMap rm = batch_rows(m, idx_d, row0, batch);
     const int64_t R = rows_of(m, idx_d, batch);
-    int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s, true);
+    int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s, fuse_head != 2);   // the one-GPU evaluation step has no backward: no sign masks
     if (rc) return rc;
     const LayerPlan& last = m->layers[m->L - 1];
     if (m->desc.model == DCV_MODEL_DEEPTICA) {

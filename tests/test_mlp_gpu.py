@@ -387,8 +387,11 @@ def _dp_rank(rank, world, port, tmpdir):
     sv, gv = eng.stats_view(), eng.grads_view()
     for i in range(steps):
         r0 = i * lb
-        if i % 2 == 0:   # the engine's own sequence: upper-layer gradients all-reduced under the layer-0 weight gradient
+        if i % 2 == 0:   # the engine's own sequence, in both forms: the two-piece one (upper-layer gradients all-reduced
+            # under the layer-0 weight gradient; the default from 32768 rows per rank up) and the one-piece one
+            os.environ["DCV_DP_OVERLAP"] = "1" if i % 4 == 0 else "0"
             eng.data_parallel_step(Xd, dist, lb * world, row0=r0, batch=lb)
+            del os.environ["DCV_DP_OVERLAP"]
         else:            # the same step written out with one gradient all-reduce
             eng.forward(Xd, row0=r0, batch=lb)
             dist.all_reduce(sv, op=dist.ReduceOp.SUM)

@@ -565,9 +565,23 @@ extern "C" int dcv_kmeans_step(const double* P_d, int64_t n, int32_t d, const do
     const size_t lds = ((size_t)k * d + k + 4 * W + 2 * kKmThreads) * sizeof(double);
     double* part = static_cast<double*>(ws_d);
     static const bool no_reg = [] { const char* e = getenv("DCV_KMEANS_ATOMIC"); return e && e[0] == '1'; }();   // diagnostic: general kernel
-    if (km_reg_fn_t reg = no_reg ? nullptr : km_reg_fn(d, k))
-        hipLaunchKernelGGL(reg, dim3(nb), dim3(kKmThreads), 0, s, P_d, n, offset_d, centers_d, (int)k, labels_d, mindist_d, part);
-    else
+    if (km_reg_fn_t reg = no_reg ? nullptr : km_reg_fn(d, k)) {
+        // One round of the chip: the register kernel holds ~150 VGPRs (3 blocks per CU), and 1024 equal blocks on 768
+        // slots is two rounds with the second a third full (3.5 TB/s).  Blocks = CUs x resident blocks per CU.
+        int nbr = nb;
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(reg), kKmThreads, 0) == hipSuccess && per_cu > 0) {
+            const int64_t one_round = (int64_t)num_cus() * per_cu;
+            if (nbr > one_round) nbr = (int)one_round;
+        } else {
+            (void)hipGetLastError();
+        }
+        hipLaunchKernelGGL(reg, dim3(nbr), dim3(kKmThreads), 0, s, P_d, n, offset_d, centers_d, (int)k, labels_d, mindist_d, part);
+        DCV_CHECK_LAUNCH();
+        hipLaunchKernelGGL(kmeans_final_kernel, dim3(W + 2), dim3(256), 0, s, part, nbr, W + 2, acc_d);
+        DCV_CHECK_LAUNCH();
+        return DCV_OK;
+    } else
         hipLaunchKernelGGL(kmeans_step_kernel, dim3(nb), dim3(kKmThreads), lds, s, P_d, n, d, offset_d, centers_d, k, labels_d, mindist_d, part);
     DCV_CHECK_LAUNCH();
     hipLaunchKernelGGL(kmeans_final_kernel, dim3(W + 2), dim3(256), 0, s, part, nb, W + 2, acc_d);

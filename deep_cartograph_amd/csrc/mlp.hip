@@ -1017,14 +1017,14 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
     const int t = threadIdx.x;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < R ? r0 + rows_per_block : R;
-    // the block's kSseRows x F elements flat over the threads, four independent element loads in flight per thread
+    // the block's rows x F elements flat over the threads, eight independent element loads in flight per thread
     // (a thread that walked its rows one after the other spent the kernel waiting: 16 dependent round trips, 27 us)
     double s = 0.0;
     const int per_block = (int)(r1 - r0) * F;
-    for (int e0 = t; e0 < per_block; e0 += 4 * 256) {
-        float ev[4];
+    for (int e0 = t; e0 < per_block; e0 += 8 * 256) {
+        float ev[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + 256 * u;
             ev[u] = 0.f;
             if (e < per_block) {
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) s += (double)ev[u] * (double)ev[u];
+        for (int u = 0; u < 8; ++u) s += (double)ev[u] * (double)ev[u];
     }
     red[t] = s;
     __syncthreads();
@@ -1665,9 +1665,13 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
         hipLaunchKernelGGL(sum_partials_kernel, dim3(m->stats_len), dim3(64), 0, s, m->spart, nb, m->stats_len, m->stats);
         DCV_CHECK_LAUNCH();
     } else {
-        // about 32 elements per thread, at most 512 blocks: every block ends on one ticket (an atomic on one address costs
-        // ~70 ns and they serialise: 1024 blocks measured 81 us for a 2 MB pass), never fewer than kSseRows rows per block
-        int64_t want = cdiv(R * (int64_t)m->desc.dims[0], 256 * 32);
+        // Two opposing costs: every block ends on a release fence + ticket (~70 ns apiece, serialised: 1024 blocks measured
+        // 81 us for a 2 MB pass), and every 8 elements per thread are one more round trip of loads (64 blocks x 32 elements
+        // per thread measured 27 us at 4096 x 128).  16 elements per thread, at most 128 blocks up to 4M elements, then
+        // 64 elements per thread up to 512 blocks; never fewer than kSseRows rows per block.
+        const int64_t elems = R * (int64_t)m->desc.dims[0];
+        int64_t want = cdiv(elems, 256 * 16);
+        if (want > 128) want = cdiv(elems, 256 * 64) > 128 ? cdiv(elems, 256 * 64) : 128;
         if (want > 512) want = 512;
         if (want < 1) want = 1;
         int64_t rpb = cdiv(R, want);

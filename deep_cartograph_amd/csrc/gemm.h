@@ -1205,7 +1205,9 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) mine[((i * FN + j) * 16 + e) * 256] = acc[0][i][j][e];
+#ifndef DCV_ABL_NOFENCE   // diagnostic (results may be stale): what the release fence of the tail chunks costs
             __threadfence();
+#endif
             __syncthreads();
             int* flag = reinterpret_cast<int*>(lds);
             if (t == 0) {

@@ -126,7 +126,7 @@ struct GemmDims {
     // tile's contraction is cut into tail_split chunks of k_chunk, one extra (short-lived) workgroup each, instead of
     // one full-length workgroup that would share a CU's SIMDs with a regular one for the whole launch.  Every chunk
     // leaves its raw accumulators in tail_ws; the last to arrive (ticket in tail_cnt) adds them up in chunk order and
-    // runs the epilogue.  0 = off.
+    // runs the epilogue.  0 = off.  tail_ws / tail_cnt must be UNCACHED device memory (alloc_tail_ws).
     int tail_split = 0;
     float* tail_ws = nullptr;
     unsigned* tail_cnt = nullptr;
@@ -1205,9 +1205,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
                     for (int e = 0; e < 16; ++e) mine[((i * FN + j) * 16 + e) * 256] = acc[0][i][j][e];
-#ifndef DCV_ABL_NOFENCE   // diagnostic (results may be stale): what the release fence of the tail chunks costs
-            __threadfence();
-#endif
+            // The workspace and the tickets live in UNCACHED device memory (hipDeviceMallocUncached; TailWs): stores and
+            // loads go to memory, so workgroups on other XCDs see them without an L2 write-back.  What is needed is that
+            // every thread's stores are complete before the ticket is taken: a workgroup-scope release (s_waitcnt) + the
+            // barrier.  (An agent-scope __threadfence here costs 2.5-3 us per launch: 25.3 vs 21.5 us at 8202 x 256 x 512.)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             int* flag = reinterpret_cast<int*>(lds);
             if (t == 0) {
@@ -1220,7 +1222,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
             const bool last = *flag != 0;
             __syncthreads();   // the flag word is part of the epilogue's staging area
             if (!last) return;
-            __threadfence();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll

@@ -1381,13 +1381,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         for (int i = 0; i < dl; ++i) eye[(size_t)i * dl + i] = 1.f;
         e = hipMemcpy(m->ident, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) {   // tail-tile workspace: up to 8 column tiles x kTailMaxSplit chunks of a 128 x 128 tile's accumulators
-        m->tail.max_tiles_n = 8;
-        m->tail.cap = (int64_t)m->tail.max_tiles_n * kTailMaxSplit * 64 * 256;
-        e = hipMalloc(reinterpret_cast<void**>(&m->tail.ws), (size_t)m->tail.cap * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&m->tail.cnt), m->tail.max_tiles_n * sizeof(unsigned));
-        if (e == hipSuccess) e = hipMemset(m->tail.cnt, 0, m->tail.max_tiles_n * sizeof(unsigned));
-    }
+    if (e == hipSuccess) (void)alloc_tail_ws(&m->tail, 8);   // up to 8 column tiles; uncached memory; on failure the tail cut stays off
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("dcv_mlp_create: initialisation failed: %s", hipGetErrorString(e));

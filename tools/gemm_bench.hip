@@ -113,11 +113,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(Hb, 0, (size_t)R * H1 * 4));
     hipStream_t s = 0;
     TailWs tw;   // workspace of the contraction-split tail tile, as the engine owns one (DCV_BENCH_NOTAIL=1: none)
-    tw.cap = 8ll * 16 * 64 * 256;
-    tw.max_tiles_n = 8;
-    CK(hipMalloc(&tw.ws, (size_t)tw.cap * 4));
-    CK(hipMalloc(&tw.cnt, 8 * sizeof(unsigned)));
-    CK(hipMemset(tw.cnt, 0, 8 * sizeof(unsigned)));
+    if (!alloc_tail_ws(&tw, 8)) { printf("uncached tail workspace: allocation failed\n"); return 1; }
     const TailWs* twp = getenv("DCV_BENCH_NOTAIL") ? nullptr : &tw;
     const int it = argc > 2 ? atoi(argv[2]) : 20;
     if (argc > 3 && !strcmp(argv[3], "cov")) {   // lagged covariance: X[R,256]^T x (X, X shifted by 10 rows), two B operands

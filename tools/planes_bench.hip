@@ -89,11 +89,7 @@ int main(int argc, char** argv) {
 
     {   // contraction-split tail tile (GemmDims::tail_split): only the rows of the ragged last tile may differ, by rounding
         TailWs tw;
-        tw.cap = 8ll * kTailMaxSplit * 64 * 256;
-        tw.max_tiles_n = 8;
-        CK(hipMalloc(&tw.ws, (size_t)tw.cap * 4));
-        CK(hipMalloc(&tw.cnt, 8 * sizeof(unsigned)));
-        CK(hipMemset(tw.cnt, 0, 8 * sizeof(unsigned)));
+        if (!alloc_tail_ws(&tw, 8)) { printf("uncached tail workspace: allocation failed\n"); return 1; }
         CK(hipMemset(C1, 0xff, (size_t)M * N * 4));
         rc = launch_gemm<kNT, EpiBiasAct>(a, b, M, N, K, 0, e1, s, nullptr, &tw);
         if (rc) { printf("tail launch failed: %s\n", dcv_last_error()); return 1; }
@@ -117,6 +113,29 @@ int main(int argc, char** argv) {
         std::vector<float> hc2(hc1.size());
         CK(hipMemcpy(hc2.data(), C1, hc2.size() * 4, hipMemcpyDeviceToHost));
         printf("  tail k-split run-to-run: %s\n", memcmp(hc1.data(), hc2.data(), hc1.size() * 4) == 0 ? "bit-identical" : "DIFFERENT");
+        if (getenv("DCV_TAIL_STRESS")) {   // alternate two different A operands: a stale partial of the other one would change bits
+            float* A2;
+            CK(hipMalloc(&A2, (size_t)M * K * 4));
+            std::vector<float> h2(h.size());
+            for (size_t i = 0; i < h.size(); ++i) h2[i] = h[i] * 1.7f + 0.3f;
+            CK(hipMemcpy(A2, h2.data(), h2.size() * 4, hipMemcpyHostToDevice));
+            const Operand a2 = make_operand(A2, K, K);
+            const size_t tail0 = (size_t)(M / 64 * 64) * N, ntail = hc1.size() - tail0;
+            std::vector<float> refA(hc1.begin() + tail0, hc1.end()), refB(ntail), got(ntail);
+            launch_gemm<kNT, EpiBiasAct>(a2, b, M, N, K, 0, e1, s, nullptr, &tw);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(refB.data(), C1 + tail0, ntail * 4, hipMemcpyDeviceToHost));
+            const int iters = atoi(getenv("DCV_TAIL_STRESS"));
+            int bad = 0;
+            for (int r = 0; r < iters; ++r) {
+                const bool useA = (r * 7 % 3) != 0;
+                launch_gemm<kNT, EpiBiasAct>(useA ? a : a2, b, M, N, K, 0, e1, s, nullptr, &tw);
+                CK(hipMemcpyAsync(got.data(), C1 + tail0, ntail * 4, hipMemcpyDeviceToHost, s));
+                CK(hipStreamSynchronize(s));
+                if (memcmp(got.data(), (useA ? refA : refB).data(), ntail * 4) != 0) ++bad;
+            }
+            printf("  tail stress: %d of %d launches with alternating operands differ from their reference\n", bad, iters);
+        }
     }
     {   // the FP32-input MFMA flavour of the same product: agreement to fp32 rounding
         set_gemm_split(false);

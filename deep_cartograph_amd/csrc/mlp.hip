@@ -751,12 +751,15 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
     if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
     // the block that finishes last adds the partials up in block order (no second launch; same sums whichever
     // block it is)
-    __threadfence();
+    // `part` and `ticket` are uncached device memory (dmalloc_uncached): visible across XCDs without an L2 write-back, so
+    // a workgroup-scope release -- this block's stores are complete -- is all the ticket needs (an agent-scope
+    // __threadfence costs ~70 ns per block, serialised)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_last) {
-        __threadfence();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         // partials of the other blocks come from memory (1-2 us each): G thread groups take the blocks b = g, g + G, ...
         // with several loads in flight, then W threads add the G group sums in group order (fixed order: deterministic)
         constexpr int G = 256 / W;
@@ -1045,7 +1048,7 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
     if (t == 0) part[blockIdx.x] = red[0];
     if (ticket == nullptr) return;
     __shared__ int is_last;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // part / ticket: uncached memory, see tica_stats_rows_kernel
     if (t == 0) {
         const unsigned prev = atomicAdd(ticket, 1u);
         is_last = prev == gridDim.x - 1;
@@ -1053,7 +1056,7 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
     }
     __syncthreads();
     if (!is_last) return;
-    __threadfence();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     if (t < 64) {   // one wave, the arithmetic of sum_partials_kernel: lanes over the blocks, shuffle tree
         double tot = 0.0;
         for (int b = t; b < (int)gridDim.x; b += 64) tot += __builtin_nontemporal_load(part + b);
@@ -1221,6 +1224,17 @@ static void mlp_free(dcv_mlp* m) {
     delete m;
 }
 
+// uncached (fine-grained) device memory: for buffers that workgroups of one launch exchange through (ticketed partials)
+template <class T>
+static int dmalloc_uncached(T** p, size_t count) {
+    *p = nullptr;
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T), hipDeviceMallocUncached);
+    if (e != hipSuccess) {
+        set_error("hipExtMallocWithFlags(uncached) of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return DCV_ENOMEM;
+    }
+    return DCV_OK;
+}
 template <class T>
 static int dmalloc(T** p, size_t count) {
     *p = nullptr;
@@ -1352,9 +1366,9 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     if (rc == DCV_OK) rc = dmalloc(&m->dZ[1], (size_t)m->rows_cap * m->ld_dz);
     if (rc == DCV_OK) rc = dmalloc(&m->stats, (size_t)m->stats_len);
     if (rc == DCV_OK) rc = dmalloc(&m->gradp, (size_t)(2 * kMaxTicaDim + 2 * kMaxTicaDim * kMaxTicaDim));
-    if (rc == DCV_OK) rc = dmalloc(&m->spart, (size_t)m->spart_blocks * m->stats_len);
+    if (rc == DCV_OK) rc = dmalloc_uncached(&m->spart, (size_t)m->spart_blocks * m->stats_len);   // ticketed partials: see tica_stats_rows_kernel
     if (rc == DCV_OK) rc = dmalloc(&m->log_count, 1);
-    if (rc == DCV_OK) rc = dmalloc(&m->ticket, 1);
+    if (rc == DCV_OK) rc = dmalloc_uncached(&m->ticket, 1);
     if (rc == DCV_OK) rc = dmalloc(&m->feat_range, (size_t)desc->dims[0]);
     if (rc == DCV_OK) rc = dmalloc(&m->ident, (size_t)dl * dl);
     if (rc == DCV_OK) rc = dmalloc(&m->zeros_d, (size_t)dl);

@@ -26,6 +26,7 @@
 #pragma once
 #include <type_traits>
 #include "common.h"
+#include "handoff.h"
 
 namespace dcv {
 
@@ -126,7 +127,7 @@ struct GemmDims {
     // tile's contraction is cut into tail_split chunks of k_chunk, one extra (short-lived) workgroup each, instead of
     // one full-length workgroup that would share a CU's SIMDs with a regular one for the whole launch.  Every chunk
     // leaves its raw accumulators in tail_ws; the last to arrive (ticket in tail_cnt) adds them up in chunk order and
-    // runs the epilogue.  0 = off.  tail_ws / tail_cnt must be UNCACHED device memory (alloc_tail_ws).
+    // runs the epilogue.  0 = off.  The hand-off between the chunk workgroups is handoff.h's (ordinary device memory).
     int tail_split = 0;
     float* tail_ws = nullptr;
     unsigned* tail_cnt = nullptr;
@@ -1204,25 +1205,14 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) mine[((i * FN + j) * 16 + e) * 256] = acc[0][i][j][e];
-            // The workspace and the tickets live in UNCACHED device memory (hipDeviceMallocUncached; TailWs): stores and
-            // loads go to memory, so workgroups on other XCDs see them without an L2 write-back.  What is needed is that
-            // every thread's stores are complete before the ticket is taken: a workgroup-scope release (s_waitcnt) + the
-            // barrier.  (An agent-scope __threadfence here costs 2.5-3 us per launch: 25.3 vs 21.5 us at 8202 x 256 x 512.)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            int* flag = reinterpret_cast<int*>(lds);
-            if (t == 0) {
-                const unsigned prev = atomicAdd(d.tail_cnt + tile_n, 1u);
-                const bool last = prev == (unsigned)(S - 1);
-                if (last) d.tail_cnt[tile_n] = 0u;   // ready for the next launch on this stream
-                *flag = last ? 1 : 0;
-            }
-            __syncthreads();
-            const bool last = *flag != 0;
+                    for (int e = 0; e < 16; ++e) handoff_store(mine + ((i * FN + j) * 16 + e) * 256, acc[0][i][j][e]);
+            // Guide-form hand-off (handoff.h): write-through payload stores, every wave drains them, barrier, one
+            // agent-scope ticket; the last arriver acquires at agent scope and reads the chunks with sc1 loads.
+            // (Round 2 had a workgroup-scope release here: it orders nothing between workgroups, and hipcc emitted no
+            // s_waitcnt vmcnt(0) between the payload stores and the ticket.)
+            const bool last = handoff_arrive_last(d.tail_cnt + tile_n, (unsigned)S, reinterpret_cast<unsigned*>(lds));
             __syncthreads();   // the flag word is part of the epilogue's staging area
             if (!last) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -1236,7 +1226,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[0][i][j][e] += __builtin_nontemporal_load(part + ((i * FN + j) * 16 + e) * 256);
+                        for (int e = 0; e < 16; ++e) acc[0][i][j][e] += handoff_load(part + ((i * FN + j) * 16 + e) * 256);
             }
         }
     }

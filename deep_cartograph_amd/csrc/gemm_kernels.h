@@ -398,14 +398,14 @@ struct TailWs {
 #define DCV_TAIL_MAXSPLIT 4   // measured at 8202 x 256 x 512: 2 chunks 26.5 us, 3: 25.8, 4: 25.5, 6: 25.4, 8: 26-28, 16: 34
 #endif
 constexpr int kTailMaxSplit = DCV_TAIL_MAXSPLIT;
-// Uncached (fine-grained) device memory for a TailWs: the chunk workgroups of one launch run on different XCDs, whose L2s
-// are not coherent with each other for ordinary allocations.  On failure the TailWs stays empty (= tail cut disabled).
+// Workspace of the hand-off between the chunk workgroups of a tail tile (handoff.h): ordinary device memory, the tickets
+// zeroed once here (the last arriver of every launch leaves them zero).  On failure the TailWs stays empty (= tail cut disabled).
 inline bool alloc_tail_ws(TailWs* tw, int max_tiles_n) {
     *tw = TailWs{};
     const int64_t cap = (int64_t)max_tiles_n * kTailMaxSplit * 64 * 256;   // a 128 x 128 tile's accumulators per chunk
     void *ws = nullptr, *cnt = nullptr;
-    if (hipExtMallocWithFlags(&ws, (size_t)cap * sizeof(float), hipDeviceMallocUncached) != hipSuccess ||
-        hipExtMallocWithFlags(&cnt, (size_t)max_tiles_n * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess ||
+    if (hipMalloc(&ws, (size_t)cap * sizeof(float)) != hipSuccess ||
+        hipMalloc(&cnt, (size_t)(max_tiles_n + 3) / 4 * 4 * sizeof(unsigned)) != hipSuccess ||
         hipMemset(cnt, 0, (size_t)max_tiles_n * sizeof(unsigned)) != hipSuccess) {
         (void)hipGetLastError();
         if (ws) (void)hipFree(ws);

@@ -748,18 +748,11 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
         }
     }
     __syncthreads();
-    if (t < W) part[(int64_t)blockIdx.x * W + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    if (t < W) handoff_store(part + (int64_t)blockIdx.x * W + t, ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t]);
     // the block that finishes last adds the partials up in block order (no second launch; same sums whichever
-    // block it is)
-    // `part` and `ticket` are uncached device memory (dmalloc_uncached): visible across XCDs without an L2 write-back, so
-    // a workgroup-scope release -- this block's stores are complete -- is all the ticket needs (an agent-scope
-    // __threadfence costs ~70 ns per block, serialised)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    if (t == 0) s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (s_last) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // block it is).  Hand-off between the blocks: handoff.h (write-through partials, drained by every wave before the
+    // barrier and the agent-scope ticket; the last arriver acquires at agent scope and reads with sc1 loads).
+    if (handoff_arrive_last(ticket, gridDim.x, &s_last)) {
         // partials of the other blocks come from memory (1-2 us each): G thread groups take the blocks b = g, g + G, ...
         // with several loads in flight, then W threads add the G group sums in group order (fixed order: deterministic)
         constexpr int G = 256 / W;
@@ -767,8 +760,17 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
         const int g = t / W, o = t - g * W;
         if (g < G) {
             double s = 0.0;
-#pragma unroll 4
-            for (unsigned b = g; b < gridDim.x; b += G) s += part[(int64_t)b * W + o];
+            for (unsigned b0 = g; b0 < gridDim.x; b0 += 8 * G) {   // eight loads in flight, added in block order
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned b = b0 + (unsigned)u * G;
+                    v[u] = handoff_load(part + (int64_t)(b < gridDim.x ? b : b0) * W + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + (unsigned)u * G < gridDim.x) s += v[u];
+            }
             s_grp[g][o] = s;
         }
         __syncthreads();
@@ -779,7 +781,6 @@ __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __res
             out[t] = s;
             red[0][t] = s;
         }
-        if (t == 0) *ticket = 0u;
         if (fused.on) {
             __syncthreads();
             if (wave == 0)
@@ -1045,21 +1046,16 @@ __global__ __launch_bounds__(256) void ae_sse_kernel(const float* __restrict__ Y
         if (t < off) red[t] += red[t + off];
         __syncthreads();
     }
-    if (t == 0) part[blockIdx.x] = red[0];
-    if (ticket == nullptr) return;
-    __shared__ int is_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // part / ticket: uncached memory, see tica_stats_rows_kernel
-    if (t == 0) {
-        const unsigned prev = atomicAdd(ticket, 1u);
-        is_last = prev == gridDim.x - 1;
-        if (is_last) *ticket = 0u;
+    if (ticket == nullptr) {
+        if (t == 0) part[blockIdx.x] = red[0];
+        return;
     }
-    __syncthreads();
-    if (!is_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (t == 0) handoff_store(part + blockIdx.x, red[0]);
+    __shared__ unsigned is_last;
+    if (!handoff_arrive_last(ticket, gridDim.x, &is_last)) return;   // handoff.h; see tica_stats_rows_kernel
     if (t < 64) {   // one wave, the arithmetic of sum_partials_kernel: lanes over the blocks, shuffle tree
         double tot = 0.0;
-        for (int b = t; b < (int)gridDim.x; b += 64) tot += __builtin_nontemporal_load(part + b);
+        for (int b = t; b < (int)gridDim.x; b += 64) tot += handoff_load(part + b);
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
         if (t == 0) {
             out[0] = tot;
@@ -1224,17 +1220,6 @@ static void mlp_free(dcv_mlp* m) {
     delete m;
 }
 
-// uncached (fine-grained) device memory: for buffers that workgroups of one launch exchange through (ticketed partials)
-template <class T>
-static int dmalloc_uncached(T** p, size_t count) {
-    *p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(p), (count ? count : 1) * sizeof(T), hipDeviceMallocUncached);
-    if (e != hipSuccess) {
-        set_error("hipExtMallocWithFlags(uncached) of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
-        return DCV_ENOMEM;
-    }
-    return DCV_OK;
-}
 template <class T>
 static int dmalloc(T** p, size_t count) {
     *p = nullptr;
@@ -1366,9 +1351,9 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     if (rc == DCV_OK) rc = dmalloc(&m->dZ[1], (size_t)m->rows_cap * m->ld_dz);
     if (rc == DCV_OK) rc = dmalloc(&m->stats, (size_t)m->stats_len);
     if (rc == DCV_OK) rc = dmalloc(&m->gradp, (size_t)(2 * kMaxTicaDim + 2 * kMaxTicaDim * kMaxTicaDim));
-    if (rc == DCV_OK) rc = dmalloc_uncached(&m->spart, (size_t)m->spart_blocks * m->stats_len);   // ticketed partials: see tica_stats_rows_kernel
+    if (rc == DCV_OK) rc = dmalloc(&m->spart, (size_t)m->spart_blocks * m->stats_len);   // ticketed partials: handoff.h
     if (rc == DCV_OK) rc = dmalloc(&m->log_count, 1);
-    if (rc == DCV_OK) rc = dmalloc_uncached(&m->ticket, 1);
+    if (rc == DCV_OK) rc = dmalloc(&m->ticket, 4);
     if (rc == DCV_OK) rc = dmalloc(&m->feat_range, (size_t)desc->dims[0]);
     if (rc == DCV_OK) rc = dmalloc(&m->ident, (size_t)dl * dl);
     if (rc == DCV_OK) rc = dmalloc(&m->zeros_d, (size_t)dl);
@@ -1385,7 +1370,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     if (e == hipSuccess) e = hipMemset(m->grads, 0, m->n_params * sizeof(float));
     if (e == hipSuccess && reset_opt_state(m, nullptr) != DCV_OK) e = hipErrorUnknown;
     if (e == hipSuccess) e = hipMemset(m->log_count, 0, sizeof(int));
-    if (e == hipSuccess) e = hipMemset(m->ticket, 0, sizeof(unsigned));
+    if (e == hipSuccess) e = hipMemset(m->ticket, 0, 4 * sizeof(unsigned));
     if (e == hipSuccess) e = hipMemset(m->zeros_d, 0, dl * sizeof(float));
     if (e == hipSuccess) e = hipMemset(m->ident, 0, (size_t)dl * dl * sizeof(float));
     if (e == hipSuccess) {
@@ -1395,7 +1380,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         for (int i = 0; i < dl; ++i) eye[(size_t)i * dl + i] = 1.f;
         e = hipMemcpy(m->ident, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice);
     }
-    if (e == hipSuccess) (void)alloc_tail_ws(&m->tail, 8);   // up to 8 column tiles; uncached memory; on failure the tail cut stays off
+    if (e == hipSuccess) (void)alloc_tail_ws(&m->tail, 8);   // up to 8 column tiles; on failure the tail cut stays off
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
         set_error("dcv_mlp_create: initialisation failed: %s", hipGetErrorString(e));

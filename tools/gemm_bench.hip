@@ -113,7 +113,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(Hb, 0, (size_t)R * H1 * 4));
     hipStream_t s = 0;
     TailWs tw;   // workspace of the contraction-split tail tile, as the engine owns one (DCV_BENCH_NOTAIL=1: none)
-    if (!alloc_tail_ws(&tw, 8)) { printf("uncached tail workspace: allocation failed\n"); return 1; }
+    if (!alloc_tail_ws(&tw, 8)) { printf("tail workspace: allocation failed\n"); return 1; }
     const TailWs* twp = getenv("DCV_BENCH_NOTAIL") ? nullptr : &tw;
     const int it = argc > 2 ? atoi(argv[2]) : 20;
     if (argc > 3 && !strcmp(argv[3], "cov")) {   // lagged covariance: X[R,256]^T x (X, X shifted by 10 rows), two B operands

@@ -89,7 +89,7 @@ int main(int argc, char** argv) {
 
     {   // contraction-split tail tile (GemmDims::tail_split): only the rows of the ragged last tile may differ, by rounding
         TailWs tw;
-        if (!alloc_tail_ws(&tw, 8)) { printf("uncached tail workspace: allocation failed\n"); return 1; }
+        if (!alloc_tail_ws(&tw, 8)) { printf("tail workspace: allocation failed\n"); return 1; }
         CK(hipMemset(C1, 0xff, (size_t)M * N * 4));
         rc = launch_gemm<kNT, EpiBiasAct>(a, b, M, N, K, 0, e1, s, nullptr, &tw);
         if (rc) { printf("tail launch failed: %s\n", dcv_last_error()); return 1; }

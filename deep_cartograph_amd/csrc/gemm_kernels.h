@@ -302,52 +302,84 @@ struct EpiSlabSum : EpiSlab {
 inline bool quad_ok(const void* p, int64_t ld) { return (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(p) & 15) == 0); }
 
 // ------------------------------------------------------------------ kernels
-// grid.x = tiles_m * tiles_n (tile_n fastest), grid.z = k splits (TN only)
-template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
-    extern __shared__ __attribute__((aligned(16))) float lds_f[];
-    // XCD-aware block -> (tile, split) map.  Blocks b and b + 8 are observed to share an XCD (and its
-    // L2); the workgroups that read the same rows -- the column tiles of one row tile (NT / NN), the
-    // output tiles of one contraction chunk (TN) -- are therefore given ids that are congruent mod 8.
-    // Placement is a speed heuristic only: any dispatch order computes the same result.
-    int tile_m, tile_n, tail_chunk = -1;
-    int64_t k_begin = 0, k_end = d.K;
+// XCD-aware block -> (tile, split) map.  Blocks b and b + 8 are observed to share an XCD (and its
+// L2); the workgroups that read the same rows -- the column tiles of one row tile (NT / NN), the
+// output tiles of one contraction chunk (TN) -- are therefore given ids that are congruent mod 8.
+// Placement is a speed heuristic only: any dispatch order computes the same result.
+// `lin` is the linear workgroup index of the product: blockIdx.x for the row-tiled forms (NT / NN, tail chunks
+// behind the regular tiles), blockIdx.z * tiles + blockIdx.x for the split-K form (TN).
+struct BlockMap {
+    int tile_m, tile_n, tail_chunk, split;
+    int64_t k_begin, k_end;
+};
+template <int MODE>
+__device__ __forceinline__ BlockMap map_block(const GemmDims& d, int lin) {
+    BlockMap bm;
+    bm.tail_chunk = -1;
+    bm.split = 0;
+    bm.k_begin = 0;
+    bm.k_end = d.K;
     if constexpr (MODE == kTN) {
         const int T = d.tiles_m * d.tiles_n;
-        const int splits = gridDim.z;
-        int tile = blockIdx.x, split = blockIdx.z;
+        int tile = lin % T, split = lin / T;
         if (d.xcd_remap) {
-            const int lin = blockIdx.z * T + blockIdx.x;
             const int xcd = lin & 7, q = lin >> 3;
             tile = q % T;
             split = (q / T) * 8 + xcd;
         }
-        (void)splits;
-        tile_m = tile / d.tiles_n;
-        tile_n = tile - tile_m * d.tiles_n;
-        k_begin = (int64_t)split * d.k_chunk;
-        k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
-        if constexpr (std::is_base_of<EpiSlab, Epi>::value) epi.z = split;
+        bm.tile_m = tile / d.tiles_n;
+        bm.tile_n = tile - bm.tile_m * d.tiles_n;
+        bm.split = split;
+        bm.k_begin = (int64_t)split * d.k_chunk;
+        bm.k_end = bm.k_begin + d.k_chunk < d.K ? bm.k_begin + d.k_chunk : d.K;
     } else {
-        int tile = blockIdx.x;
+        const int tile = lin;
         const int regular = d.tail_split > 0 ? (d.tiles_m - 1) * d.tiles_n : d.tiles_m * d.tiles_n;
         if (tile >= regular) {   // a contraction chunk of the ragged last row tile
             const int j = tile - regular;
-            tile_m = d.tiles_m - 1;
-            tile_n = j % d.tiles_n;
-            tail_chunk = j / d.tiles_n;
-            k_begin = (int64_t)tail_chunk * d.k_chunk;
-            k_end = k_begin + d.k_chunk < d.K ? k_begin + d.k_chunk : d.K;
+            bm.tile_m = d.tiles_m - 1;
+            bm.tile_n = j % d.tiles_n;
+            bm.tail_chunk = j / d.tiles_n;
+            bm.k_begin = (int64_t)bm.tail_chunk * d.k_chunk;
+            bm.k_end = bm.k_begin + d.k_chunk < d.K ? bm.k_begin + d.k_chunk : d.K;
         } else if (d.xcd_remap) {
             const int xcd = tile & 7, q = tile >> 3;
-            tile_n = q % d.tiles_n;
-            tile_m = (q / d.tiles_n) * 8 + xcd;
+            bm.tile_n = q % d.tiles_n;
+            bm.tile_m = (q / d.tiles_n) * 8 + xcd;
         } else {
-            tile_m = tile / d.tiles_n;
-            tile_n = tile - tile_m * d.tiles_n;
+            bm.tile_m = tile / d.tiles_n;
+            bm.tile_n = tile - bm.tile_m * d.tiles_n;
         }
     }
-    gemm_block<MODE, Cfg, NB, VEC, GATHER, Epi>(A, B, lag2, d, tile_m, tile_n, k_begin, k_end, lds_f, epi, tail_chunk);
+    return bm;
+}
+
+// grid.x = tiles_m * tiles_n (tile_n fastest; + tail chunks), grid.z = k splits (TN only)
+template <int MODE, class Cfg, int NB, bool VEC, bool GATHER, class Epi>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(Operand A, Operand B, int64_t lag2, GemmDims d, Epi epi) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    const int lin = MODE == kTN ? (int)(blockIdx.z * (unsigned)(d.tiles_m * d.tiles_n) + blockIdx.x) : (int)blockIdx.x;
+    const BlockMap bm = map_block<MODE>(d, lin);
+    if constexpr (MODE == kTN && std::is_base_of<EpiSlab, Epi>::value) epi.z = bm.split;
+    gemm_block<MODE, Cfg, NB, VEC, GATHER, Epi>(A, B, lag2, d, bm.tile_m, bm.tile_n, bm.k_begin, bm.k_end, lds_f, epi, bm.tail_chunk);
+}
+
+// Two independent products in ONE launch (blocks [0, blocks1) run the first, the rest the second): the weight gradient
+// (TN, split-K slabs) and the input gradient (NN) of a layer both read the same dZ and neither reads the other's
+// output; as two launches of a small-batch step each leaves part of the chip idle (256 + 516 workgroups at 8202 rows)
+// and pays its own launch ramp and drain.
+template <class Cfg1, class Cfg2>
+__global__ __launch_bounds__(256, 2) void wgrad_dgrad_kernel(Operand A1, Operand B1, GemmDims d1, EpiSlab e1, int blocks1, Operand A2, Operand B2,
+                                                           GemmDims d2, EpiActGrad e2) {
+    extern __shared__ __attribute__((aligned(16))) float lds_f[];
+    if ((int)blockIdx.x < blocks1) {
+        const BlockMap bm = map_block<kTN>(d1, (int)blockIdx.x);
+        e1.z = bm.split;
+        gemm_block<kTN, Cfg1, 1, true, false, EpiSlab>(A1, B1, 0, d1, bm.tile_m, bm.tile_n, bm.k_begin, bm.k_end, lds_f, e1, -1);
+    } else {
+        const BlockMap bm = map_block<kNN>(d2, (int)blockIdx.x - blocks1);
+        gemm_block<kNN, Cfg2, 1, true, false, EpiActGrad>(A2, B2, 0, d2, bm.tile_m, bm.tile_n, bm.k_begin, bm.k_end, lds_f, e2, bm.tail_chunk);
+    }
 }
 
 // Tile configurations, each in two arithmetic flavours (template argument S): the FP32-input MFMA
@@ -429,11 +461,18 @@ inline bool tail_split_enabled() {
     return on;
 }
 
+// Launch geometry of one product: tile counts, XCD map, tail cut, split count, loader flavour.
 // tiles_m_out (optional) receives the number of row tiles (= bias partial blocks of EpiActGrad)
-template <int MODE, class Cfg, int NB, class Epi>
-static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int64_t M, int64_t N, int64_t K,
-                           int64_t k_chunk, const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr, const TailWs* tw = nullptr) {
+struct GemmPlan {
     GemmDims d;
+    int64_t splits;
+    bool vec, gather;
+};
+template <int MODE, class Cfg, int NB, class Epi>
+static int prepare_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk, const Epi& epi,
+                        int* tiles_m_out, const TailWs* tw, GemmPlan* plan) {
+    GemmDims& d = plan->d;
+    d = GemmDims{};
     d.M = M;
     d.N = N;
     d.K = K;
@@ -468,30 +507,69 @@ static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int
             }
         }
     }
-    const int64_t splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
+    plan->splits = (MODE == kTN) ? cdiv(K, d.k_chunk) : 1;
     const int64_t tiles = (int64_t)d.tiles_m * d.tiles_n;
-    DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && splits > 0 && splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
-                (long long)tiles, (long long)splits);
+    DCV_REQUIRE(tiles > 0 && tiles < (1ll << 31) && plan->splits > 0 && plan->splits < 65536, "gemm: grid out of range (tiles=%lld splits=%lld)",
+                (long long)tiles, (long long)plan->splits);
     DCV_REQUIRE(!(Cfg::SPLIT && (A.shift || B.shift)), "gemm: a column shift needs the FP32-input MFMA flavour");
     if constexpr (std::is_base_of<EpiSlab, Epi>::value) {
         // every split writes its own slab: refuse the launch instead of writing past the caller's buffer
-        if (splits > epi.cap) {
-            set_error("gemm: %lld split-K slabs needed, the slab buffer holds %lld", (long long)splits, (long long)epi.cap);
+        if (plan->splits > epi.cap) {
+            set_error("gemm: %lld split-K slabs needed, the slab buffer holds %lld", (long long)plan->splits, (long long)epi.cap);
             return DCV_ENOMEM;
         }
     }
     // 16-byte loads: aligned operands; contraction-contiguous (MMAJOR) operands also need K % 4 == 0
     constexpr bool A_MM = (MODE == kNT || MODE == kNN), B_MM = (MODE == kNT);
-    const bool vec = A.vec_ok && B.vec_ok && (!A_MM || K % 4 == 0) && (!B_MM || K % 4 == 0) && (MODE != kTN || d.k_chunk % 1 == 0);
-    const bool gather = A.rows.idx != nullptr || B.rows.idx != nullptr;
-    if (vec && !gather) return launch_gemm_vec<MODE, Cfg, NB, true, false, Epi>(A, B, lag2, d, splits, epi, s);
-    if (vec) return launch_gemm_vec<MODE, Cfg, NB, true, true, Epi>(A, B, lag2, d, splits, epi, s);
-    return launch_gemm_vec<MODE, Cfg, NB, false, true, Epi>(A, B, lag2, d, splits, epi, s);   // scalar loads: gather-capable form
+    plan->vec = A.vec_ok && B.vec_ok && (!A_MM || K % 4 == 0) && (!B_MM || K % 4 == 0);
+    plan->gather = A.rows.idx != nullptr || B.rows.idx != nullptr;
+    return DCV_OK;
+}
+template <int MODE, class Cfg, int NB, class Epi>
+static int launch_gemm_cfg(const Operand& A, const Operand& B, int64_t lag2, int64_t M, int64_t N, int64_t K,
+                           int64_t k_chunk, const Epi& epi, hipStream_t s, int* tiles_m_out = nullptr, const TailWs* tw = nullptr) {
+    GemmPlan pl;
+    const int rc = prepare_gemm<MODE, Cfg, NB, Epi>(A, B, M, N, K, k_chunk, epi, tiles_m_out, tw, &pl);
+    if (rc) return rc;
+    if (pl.vec && !pl.gather) return launch_gemm_vec<MODE, Cfg, NB, true, false, Epi>(A, B, lag2, pl.d, pl.splits, epi, s);
+    if (pl.vec) return launch_gemm_vec<MODE, Cfg, NB, true, true, Epi>(A, B, lag2, pl.d, pl.splits, epi, s);
+    return launch_gemm_vec<MODE, Cfg, NB, false, true, Epi>(A, B, lag2, pl.d, pl.splits, epi, s);   // scalar loads: gather-capable form
 }
 
 // Picks the tile shape from the output extents.  Row-parallel products (NT / NN) fall back to
 // shorter tiles when 128-row tiles would leave CUs without two resident workgroups (small per-GPU
 // batches of a multi-GPU run); TN products get their parallelism from the split count instead.
+enum CfgPick { kPickNarrowN, kPickNarrowM, kPickHalfM, kPickQuarter, kPickBig };
+template <int MODE, bool HEAD>
+static CfgPick pick_cfg(int64_t M, int64_t N, int64_t K, int64_t k_chunk) {
+#ifdef DCV_FORCE_BIG   // diagnostic (tools/gemm_bench): every product takes the DCV_BIGCFG tile, whatever its extents
+    return kPickBig;
+#endif
+    if (N <= 32) return kPickNarrowN;
+    if (M <= 32) return kPickNarrowM;
+    if constexpr (MODE != kTN) {
+        const int64_t want = 2 * (int64_t)num_cus();
+        const int64_t tn = cdiv(N, 128);
+        if (cdiv(M, 128) * tn < want) {
+            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return kPickHalfM;
+            if (cdiv(M, 64) * tn < want / 2) return kPickNarrowM;
+            // between one and two 64 x 128 workgroups per CU (8202 rows x 256 columns: 258): 64 x 64 tiles put two waves on
+            // every SIMD, which overlap each other's split and MFMA phases (measured 22.8 -> 20.8 us at 8192 x 256 x 512)
+            if constexpr (!HEAD) {
+                static const bool quarter_off = [] { const char* e = getenv("DCV_NO_QUARTER_NT"); return e && e[0] == '1'; }();
+                if (!quarter_off && N % 64 == 0) return kPickQuarter;
+            }
+            return kPickHalfM;
+        }
+    }
+    if constexpr (MODE == kTN) {
+        // split-K product on a small grid (weight gradients of a small batch: the split count is bounded by the rows):
+        // four times the workgroups with 64 x 64 tiles (measured on the 128 x 256 x 8202 product: 17.2 -> 10.6 us)
+        const int64_t nsplit = cdiv(K, k_chunk > 0 ? k_chunk : K);
+        if (cdiv(M, 128) * cdiv(N, 128) * nsplit < (int64_t)num_cus() / 2) return kPickQuarter;
+    }
+    return kPickBig;
+}
 template <int MODE, bool S, class Epi>
 static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
                             const Epi& epi, hipStream_t s, int* tiles_m_out, const TailWs* tw = nullptr) {
@@ -500,34 +578,15 @@ static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64
 #else
     using Big = CfgBigT<S>;
 #endif
-#ifdef DCV_FORCE_BIG   // diagnostic (tools/gemm_bench): every product takes the DCV_BIGCFG tile, whatever its extents
-    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-#endif
-    if (N <= 32) return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-    if (M <= 32) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-    if constexpr (MODE != kTN) {
-        const int64_t want = 2 * (int64_t)num_cus();
-        const int64_t tn = cdiv(N, 128);
-        if (cdiv(M, 128) * tn < want) {
-            if (cdiv(M, 64) * tn >= want || M <= 64 * 4) return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-            if (cdiv(M, 64) * tn < want / 2) return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-            // between one and two 64 x 128 workgroups per CU (8202 rows x 256 columns: 258): 64 x 64 tiles put two waves on
-            // every SIMD, which overlap each other's split and MFMA phases (measured 22.8 -> 20.8 us at 8192 x 256 x 512)
-            if constexpr (!Epi::kHead) {
-                static const bool quarter_off = [] { const char* e = getenv("DCV_NO_QUARTER_NT"); return e && e[0] == '1'; }();
-                if (!quarter_off && N % 64 == 0) return launch_gemm_cfg<MODE, CfgQuarterT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-            }
-            return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-        }
+    switch (pick_cfg<MODE, Epi::kHead>(M, N, K, k_chunk)) {
+        case kPickNarrowN: return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+        case kPickNarrowM: return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+        case kPickHalfM: return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+        case kPickQuarter:
+            if constexpr (!Epi::kHead) return launch_gemm_cfg<MODE, CfgQuarterT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+            else return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+        default: return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
     }
-    if constexpr (MODE == kTN) {
-        // split-K product on a small grid (weight gradients of a small batch: the split count is bounded by the rows):
-        // four times the workgroups with 64 x 64 tiles (measured on the 128 x 256 x 8202 product: 17.2 -> 10.6 us)
-        const int64_t nsplit = cdiv(K, k_chunk > 0 ? k_chunk : K);
-        if (cdiv(M, 128) * cdiv(N, 128) * nsplit < (int64_t)num_cus() / 2)
-            return launch_gemm_cfg<MODE, CfgQuarterT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
-    }
-    return launch_gemm_cfg<MODE, Big, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 }
 
 template <int MODE, class Epi>
@@ -540,6 +599,13 @@ static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N,
     return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 #endif
 }
+
+// Weight gradient (TN, slabs) and input gradient (NN) of one layer as ONE launch (wgrad_dgrad_kernel; defined in
+// pair.hip).  Returns 1 when the pair form does not apply (the caller then launches the two products one after the
+// other), DCV_OK when both were enqueued, < 0 on error.  tiles_m_out2: row tiles of the NN product (bias partials).
+int launch_wgrad_dgrad(const Operand& A1, const Operand& B1, int64_t M1, int64_t N1, int64_t K1, int64_t k_chunk1, const EpiSlab& e1,
+                       const Operand& A2, const Operand& B2, int64_t M2, int64_t N2, int64_t K2, const EpiActGrad& e2, int* tiles_m_out2,
+                       const TailWs* tw, hipStream_t s);
 
 // ------------------------------------------------------------------ plane operands (TileCfg::PL)
 // Plane form of an fp32 matrix [rows][cols]: row r is [plane 1 | plane 2 | plane 3], each Kp = round_up(cols, 32) bf16

@@ -1828,10 +1828,6 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         Operand A = make_operand(dz_cur, m->ld_dz, p.out);
         Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
         EpiSlab epi{p.slab, p.out, p.in, 1, 0, quad_ok(p.slab, p.in), p.max_splits};
-        prof_mark(m, l, 1, 0, s);
-        int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
-        if (rc) return rc;
-        prof_mark(m, l, 1, 1, s);
         ReduceDesc& rd = ra.l[l];
         rd.slab = p.slab;
         rd.bpart = p.bpart;
@@ -1841,26 +1837,44 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         rd.out = p.out;
         rd.splits = (int)splits;
         rd.bblocks = bblocks;
-        if (l > 0) {
-            // dgrad: dZ_prev = (dZ W) * act'(H_prev)   (M = rows, N = in, K = out)
-            LayerPlan& q = m->layers[l - 1];
-            Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
-            Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
-            EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
-            if (q.mask && q.mask_rows == R) {   // written by this step's forward with the same (rows, width) => same tiling
-                eg.mask = q.mask;
-                eg.slope = q.act == DCV_ACT_LEAKY_RELU ? 0.01f : 0.f;
-            }
-            eg.drop = drop_cfg(m, l - 1);
-            eg.hscale = drop_hscale(m, l - 1);
+        if (l == 0) {
+            prof_mark(m, l, 1, 0, s);
+            int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
+            if (rc) return rc;
+            prof_mark(m, l, 1, 1, s);
+            continue;
+        }
+        // dgrad: dZ_prev = (dZ W) * act'(H_prev)   (M = rows, N = in, K = out)
+        LayerPlan& q = m->layers[l - 1];
+        Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
+        Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
+        EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
+        if (q.mask && q.mask_rows == R) {   // written by this step's forward with the same (rows, width) => same tiling
+            eg.mask = q.mask;
+            eg.slope = q.act == DCV_ACT_LEAKY_RELU ? 0.01f : 0.f;
+        }
+        eg.drop = drop_cfg(m, l - 1);
+        eg.hscale = drop_hscale(m, l - 1);
+        // the two products read the same dZ and neither reads the other's output: one launch when the pair form applies
+        prof_mark(m, l, 1, 0, s);
+        prof_mark(m, l, 2, 0, s);
+        int rc = launch_wgrad_dgrad(A, B, p.out, p.in, R, kc, epi, Ad, Bd, R, p.in, p.out, eg, &bblocks, &m->tail, s);
+        if (rc < 0) return rc;
+        if (rc == 1) {
+            rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
+            if (rc) return rc;
+            prof_mark(m, l, 1, 1, s);
             prof_mark(m, l, 2, 0, s);
             rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks, &m->tail);
             if (rc) return rc;
             prof_mark(m, l, 2, 1, s);
-            float* tmp = dz_cur;
-            dz_cur = dz_nxt;
-            dz_nxt = tmp;
+        } else {
+            prof_mark(m, l, 1, 1, s);
+            prof_mark(m, l, 2, 1, s);
         }
+        float* tmp = dz_cur;
+        dz_cur = dz_nxt;
+        dz_nxt = tmp;
     }
     OptArgs oa{};
     if (fuse_opt) oa = next_opt_args(m);

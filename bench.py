@@ -53,6 +53,11 @@ def parse():
                    help="arithmetic of the MLP products: 'split' = FP32-accurate split products on the BF16 matrix pipe "
                         "(library default), 'native' = FP32-input MFMA; the other mode is timed too (field 'other_gemm_mode')")
     p.add_argument("--other-mode-steps", type=int, default=200)
+    p.add_argument("--backend", default="nccl", help="torch.distributed backend of a multi-rank run: 'nccl' (= RCCL over xGMI; default) or "
+                                                    "'gloo' (rehearsals of the N > 1 control flow with several ranks on one GPU)")
+    p.add_argument("--config", choices=["c4", "c2"], default="c4",
+                   help="c4 (default): the headline, Deep-TICA on 10M x 512; c2: BASELINE.json configs[1], autoencoder 128-64-32-2-32-64-128 on "
+                        "1M x 128 at batch 4096 (its own metric line with roofline and cpu_baseline; one GPU)")
     return p.parse_args()
 
 
@@ -152,12 +157,14 @@ class Fit:
         if profile_every > 0:
             eng.profile_begin(sampled, 1)
         t0 = time.perf_counter()
+        self.val_timed = 0
         for i in range(steps):
             if profile_every > 1:
                 eng.profile_pause(i % profile_every != 0)
             self.train_step(i)
             if with_validation and (i + 1) % self.steps_per_epoch == 0:
                 self.validation_pass()
+                self.val_timed += self.val_steps
         self.barrier()
         elapsed = time.perf_counter() - t0
         prof = eng.profile_end() if profile_every > 0 else {}
@@ -192,6 +199,8 @@ class Fit:
                 traffic = entry.get("kernels", {}).get(name, {}).get("hbm_bytes_per_launch")
         return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel": kname, "rows_per_launch": R, "flop_per_launch": fl, "avg_ms": ms,
+                "timing_source": "HIP events recorded on the launch stream around that launch inside bench.py (dcv_mlp_profile_*), every "
+                                 "--profile-every-th timed step; rocprofv3 --kernel-trace reads ~4-5 us less per launch (profiles/)",
                 "all_kernels_ms": {k: v[1] for k, v in sorted(per.items())}, "note": note}
 
     def close(self):
@@ -211,8 +220,128 @@ def load_traffic_tables():
     return out
 
 
+def cpu_baseline_ae(Xn_host, dims, acts_enc, acts_dec, latent, batch, lr, seconds, linears, feat_range):
+    """The torch-CPU oracle of the autoencoder step (same MLP, f32, same batches) on this box's host cores, bounded."""
+    from oracle import nn as onn
+
+    F = dims[0]
+    model = onn.AEModel(dims[:latent + 1], acts_enc, None, dims[latent:], acts_dec, None, np.zeros(F, np.float32), feat_range)
+    lins = [m for m in list(model.encoder) + list(model.decoder) if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for l, (w, b) in zip(lins, linears):
+            l.weight.copy_(torch.from_numpy(w))
+            l.bias.copy_(torch.from_numpy(b))
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    xt = torch.from_numpy(Xn_host)
+    nb = max(1, xt.shape[0] // batch)
+
+    def step(i):
+        r0 = (i % nb) * batch
+        opt.zero_grad()
+        loss, _ = model.step(xt[r0:r0 + batch])
+        loss.backward()
+        opt.step()
+
+    step(0)
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        step(done + 1)
+        done += 1
+        if time.perf_counter() - t0 >= seconds or done >= 5000:
+            break
+    dt = time.perf_counter() - t0
+    return done * batch / dt, done, dt
+
+
+def main_c2(a):
+    """BASELINE.json configs[1]: autoencoder CV (2 hidden layers, dim 2) on 1M frames x 128 synthetic features, one MI355X.
+    A step = one optimiser step over 4096 frames; the fit loop is the reference's (lengths [0.8, 0.2], sequential split,
+    validation pass at every epoch end inside the timed region)."""
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd.synth import synth_features
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n, F, d, bs = 1_000_000, 128, 2, 4096
+    dims = [F, 64, 32, d, 32, 64, F]
+    acts = ["leaky_relu", "leaky_relu", None, "leaky_relu", "leaky_relu", None]
+    latent = 3
+    X = synth_features(n, F, k_slow=4, shard=0, device=dev)
+    st = hip.finalize_stats(hip.col_stats_raw(X), n)
+    std = st["std"].copy()
+    std[np.abs(std) < 1e-8] = 1.0
+    hip.normalize(X, torch.from_numpy(st["mean"]).to(dev), torch.from_numpy(std).to(dev), out=X)
+    Xn = X
+    linears = init_linears(dims, 43)
+    eng = hip.Mlp("ae", dims, acts, max_batch=bs, latent_layer=latent, lr=a.lr)
+    eng.set_linears(linears)
+    eng.set_feature_range(std.astype(np.float32))
+    n_train = int(n * 0.8) // bs * bs
+    spe, val_steps = n_train // bs, (n - n_train) // bs
+    steps = a.steps
+
+    def train_step(i):
+        eng.train_step(Xn, row0=(i % spe) * bs, batch=bs)
+
+    def validation():
+        for j in range(val_steps):
+            eng.eval_step(Xn, row0=n_train + j * bs, batch=bs)
+
+    eng.reset_log(2 * (steps + a.warmup + 64) + (steps // spe + 2) * (val_steps + 1))
+    for i in range(30 + a.warmup):
+        train_step(i)
+    torch.cuda.synchronize()
+    sampled = max(1, steps // max(1, a.profile_every)) + 1
+    eng.profile_begin(sampled, 1)
+    t0 = time.perf_counter()
+    n_val = 0
+    for i in range(steps):
+        eng.profile_pause(i % max(1, a.profile_every) != 0)
+        train_step(i)
+        if (i + 1) % spe == 0:
+            validation()
+            n_val += val_steps
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_end()
+    log = eng.read_log()
+    sw = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+    roof = None
+    if (0, "fwd") in prof:
+        ms, cnt = prof[(0, "fwd")]
+        fl = 6.0 * bs * sw
+        ach = fl / (ms / cnt * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                "traffic": None, "kernel": "snet_ae_kernel<32> (whole step fused: forward, loss, backward of a 32-row tile per workgroup, "
+                                             "v_mfma_f32_16x16x4_f32, weights resident in LDS)",
+                "flop_per_launch": fl, "avg_ms": ms / cnt, "timing_source": "HIP events on the launch stream around the fused launch (bench.py)",
+                "note": "algorithmic 6 * batch * sum(in*out) flop of one launch / its mean duration; the kernel is latency-bound at 4096 rows "
+                        "(32 rows per workgroup, 128 workgroups): the fraction is reported for the record, not as a claim of MFMA saturation"}
+    out = {"metric": "Autoencoder training frames/sec on 1Mx128 feature matrix (BASELINE.json configs[1]) at 1 GPU", "value": steps * bs / elapsed,
+           "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"Autoencoder fit (BASELINE.md C2), {n}x{F} f32 synthetic AR(1) features, MLP {'-'.join(map(str, dims))}, batch {bs}, "
+                                  f"Adam lr {a.lr}, lengths [0.8,0.2], sequential split; {n_val} validation steps inside the timed region",
+                      "frames": n, "features": F, "global_batch": bs, "steps_per_epoch": spe, "val_steps_per_epoch": val_steps,
+                      "validation_steps_timed": n_val, "params": sw},
+           "loss_first": float(log[0, 0]) if len(log) else None, "loss_last": float(log[-1, 0]) if len(log) else None, "roofline": roof}
+    if not a.no_cpu_baseline:
+        rows = min(n, 40 * bs)
+        v, done, dt = cpu_baseline_ae(Xn[:rows].cpu().numpy(), dims, acts[:latent], acts[latent:], latent, bs, a.lr, a.cpu_seconds, linears,
+                                      std.astype(np.float32))
+        out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{done} optimiser steps of the torch-CPU oracle (same autoencoder, f32, batches of {bs}) on the first {rows} frames, {dt:.1f} s"}
+    eng.close()
+    print(json.dumps(out))
+
+
 def main():
     a = parse()
+    if a.config == "c2":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
+        return main_c2(a)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -230,7 +359,10 @@ def main():
             for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531")):
                 os.environ.setdefault(k, v)
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(a.backend)
 
     from deep_cartograph_amd import hip
     from deep_cartograph_amd.synth import synth_features
@@ -268,6 +400,7 @@ def main():
     # ---- headline: the contract batch
     fit = Fit(hip, dist, Xn, dims, acts, lag, a.batch, world, a.lr, linears, n_local)
     elapsed, prof, log = fit.run(a.steps, a.warmup, a.profile_every)
+    val_timed = fit.val_timed
     head_roof = fit.roofline(prof, a.gemm_mode, traffic_tables) if rank == 0 else None
 
     # the same training steps in the other arithmetic mode (a launch-time switch of the library)
@@ -322,10 +455,11 @@ def main():
             "config": {
                 "workload": f"Deep-TICA fit (BASELINE.md C4), {a.frames}x{F} f32 synthetic AR(1) features (SURVEY 8d), MLP {'-'.join(map(str, dims))}, "
                             f"lag {lag}, global batch {a.batch} pairs, Adam lr {a.lr}, lengths [0.8,0.2], sequential split, "
-                            f"validation pass at each epoch end inside the timed region; contiguous batches evaluate the "
-                            f"batch + lag rows shared by x_t and x_lag once",
+                            f"validation pass at each epoch end the {a.steps} timed steps cross ({val_timed} validation steps inside the timed "
+                            f"region of this run); contiguous batches evaluate the batch + lag rows shared by x_t and x_lag once",
                 "frames": a.frames, "features": F, "global_batch": a.batch, "parallelism": f"frame-shard dp{world}",
-                "steps_per_epoch": steps_per_epoch, "val_steps_per_epoch": val_steps, "params": sw, "gemm_mode": a.gemm_mode,
+                "steps_per_epoch": steps_per_epoch, "val_steps_per_epoch": val_steps, "validation_steps_timed": val_timed, "params": sw,
+                "gemm_mode": a.gemm_mode,
             },
             "loss_first": float(losses[0]) if len(losses) else None,
             "loss_last_train": float(losses[-1]) if len(losses) else None,

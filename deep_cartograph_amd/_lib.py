@@ -85,6 +85,9 @@ SIGNATURES = {
     "dcv_mlp_backward": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I64, _I32, _P]),
     "dcv_mlp_apply": (C.c_int, [_P, _P]),
     "dcv_mlp_set_upper_grads_callback": (C.c_int, [_P, _P, _P]),
+    "dcv_mlp_dp_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _P, _P]),
+    "dcv_mlp_set_rank": (C.c_int, [_P, _I32]),
+    "dcv_mlp_layer_output": (C.c_int, [_P, _I32, _I64, _P, _P]),
     "dcv_mlp_train_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_eval_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_log_width": (_I32, [_P]),

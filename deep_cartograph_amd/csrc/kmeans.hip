@@ -634,7 +634,15 @@ extern "C" int dcv_nearest_point(const double* train_d, int64_t n_train, const d
         case 6: hipLaunchKernelGGL(KERNEL<6>, __VA_ARGS__); break;                                    \
         case 7: hipLaunchKernelGGL(KERNEL<7>, __VA_ARGS__); break;                                    \
         case 8: hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__); break;                                    \
-        default: set_error("k-means++ passes: d=%d (1..8) unsupported", d); return DCV_EINVAL;        \
+        case 9: hipLaunchKernelGGL(KERNEL<9>, __VA_ARGS__); break;                                    \
+        case 10: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                  \
+        case 11: hipLaunchKernelGGL(KERNEL<11>, __VA_ARGS__); break;                                  \
+        case 12: hipLaunchKernelGGL(KERNEL<12>, __VA_ARGS__); break;                                  \
+        case 13: hipLaunchKernelGGL(KERNEL<13>, __VA_ARGS__); break;                                  \
+        case 14: hipLaunchKernelGGL(KERNEL<14>, __VA_ARGS__); break;                                  \
+        case 15: hipLaunchKernelGGL(KERNEL<15>, __VA_ARGS__); break;                                  \
+        case 16: hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__); break;                                  \
+        default: set_error("k-means++ passes: d=%d (1..16) unsupported", d); return DCV_EINVAL;       \
     }
 
 extern "C" size_t dcv_kmeanspp_workspace(int64_t n, int32_t trials) {

@@ -10,81 +10,11 @@
 // kernel (deterministic), Adam is one more launch.  The d x d TICA algebra of the Deep-TICA
 // loss runs in float64 on the device from batch statistics that a data-parallel caller
 // all-reduces, so nothing returns to the host inside an epoch.
-#include "gemm_kernels.h"
-#include <vector>
+#include "mlp_state.h"
 #include <new>
 #include <math.h>
 
-namespace dcv {
-
-constexpr int kMaxTicaDim = 16;
-
-struct LayerPlan {
-    int in, out, act;
-    int64_t w_off, b_off;      // offsets into the flat parameter buffer (floats, 16-byte aligned)
-    int64_t ldh;               // row stride of the activation buffer
-    float* H;                  // [rows][ldh] post-activation output
-    // wgrad split-K
-    int64_t k_chunk_cap;       // rows per split at full capacity
-    int64_t max_splits;
-    float* slab;               // [max_splits][out][in]
-    float* bpart;              // [bias_blocks_cap][out]
-    unsigned long long* mask;  // sign mask of H in the forward epilogue's thread layout (ReLU family), or null
-    int64_t mask_rows;         // row count of the training forward that wrote it (-1: stale)
-};
-
-}  // namespace dcv
-
 using namespace dcv;
-
-struct dcv_mlp {
-    dcv_mlp_desc desc;
-    int L;
-    int d_out;                 // dims[L]
-    int64_t rows_cap;          // rows per step at max_batch
-    int64_t n_params;
-    std::vector<LayerPlan> layers;
-    float *params, *grads, *adam_m, *adam_v;
-    float* opt_aux;            // third optimiser state (amsgrad maximum / centred RMSprop gradient average) or null
-    double momentum_rt;        // beta1 (Adam family) or momentum (SGD, RMSprop): dcv_mlp_set_momentum
-    bool any_drop;             // some layer has dropout p > 0
-    bool fwd_train;            // the last forward ran in training mode (dropout active): backward must agree
-    dcv::TailWs tail;          // workspace of the contraction-split tail tile of row-tiled products (gemm.h: GemmDims::tail_split)
-    void (*upper_cb)(void*);   // data-parallel overlap hook (dcv_mlp_set_upper_grads_callback) or null
-    void* upper_cb_user;
-    bool head_done;            // the last forward already ran the d x d loss head inside its statistics launch (one-GPU steps)
-    int64_t drop_step;         // training forwards so far = step field of the next forward's dropout counters
-    int64_t cur_step;          // step field of the last training forward
-    float* dZ[2];
-    int64_t ld_dz;
-    double* stats;             // device
-    int stats_len;
-    double* gradp;             // Deep-TICA: [mu d | Gu d*d | Gv d*d | c d], float64 (see tica_dF_kernel)
-    double* spart;             // stats partials
-    int spart_blocks;
-    double* log;
-    int* log_count;
-    unsigned* ticket;          // block counter of the single-launch statistics reduction (zero between launches)
-    hipGraphExec_t gexec[4];   // instantiated step graphs (train step, forward, backward, eval step) or null
-    bool gwarm[4];             // the slot ran once outside capture (lazy module loading, first-use attributes)
-    bool graph_on;             // step graphs requested (dcv_mlp_set_graph; default from DCV_GRAPH=1)
-    bool graph_off;            // graph instantiation failed once: plain launches from then on
-    int64_t graph_launches;    // steps / half-steps that went out as one graph launch
-    bool prof_paused;          // profiling armed but skipped for the current calls (dcv_mlp_profile_pause)
-    int log_cap, log_width;
-    float* feat_range;         // AE
-    float *ident, *zeros_d, *ones_d;  // helpers for inference
-    float* proj_ws;
-    size_t proj_ws_bytes;
-    int64_t adam_t;
-    double lr;
-    // bookkeeping of the last forward (backward must match)
-    int32_t last_batch;
-    int no_row_sharing;        // diagnostic: evaluate contiguous Deep-TICA batches as two separate halves
-    // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
-    int prof_level, prof_cap, prof_step;
-    std::vector<hipEvent_t> prof_ev;  // [class][step][2], class = 3*layer + {0 fwd, 1 wgrad, 2 dgrad}
-};
 
 namespace dcv {
 
@@ -1145,7 +1075,9 @@ static DropCfg drop_cfg(const dcv_mlp* m, int layer) {
     double t = (double)p * 4294967296.0;
     if (t > 4294967295.0) t = 4294967295.0;
     if (t < 1.0) t = 1.0;
-    return DropCfg{(uint32_t)t, 1.f / (1.f - p), (uint32_t)(m->desc.seed & 0xFFFFFFFFull), (uint32_t)(m->desc.seed >> 32), (uint32_t)layer,
+    // rank r of a data-parallel run draws from its own stream (key word 1 offset by r * golden ratio): every rank holds
+    // the same seed, and with a shared key all ranks would mask their local rows alike
+    return DropCfg{(uint32_t)t, 1.f / (1.f - p), (uint32_t)(m->desc.seed & 0xFFFFFFFFull), (uint32_t)(m->desc.seed >> 32) + 0x9E3779B9u * m->drop_rank, (uint32_t)layer,
                    (uint32_t)m->cur_step};
 }
 static float drop_hscale(const dcv_mlp* m, int layer) {
@@ -1210,6 +1142,7 @@ static void head_plan(const dcv_mlp* m, int64_t R, int64_t* rows_per_block, int6
 
 static void mlp_free(dcv_mlp* m) {
     if (!m) return;
+    snet_free(m);
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->opt_aux); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
@@ -1295,6 +1228,9 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->tail = dcv::TailWs{};
     m->drop_step = 0;
     m->cur_step = 0;
+    m->drop_rank = 0;
+    m->snet = nullptr;
+    m->snet_tried = false;
     m->prof_level = m->prof_cap = m->prof_step = 0;
     for (int i = 0; i < 4; ++i) { m->gexec[i] = nullptr; m->gwarm[i] = false; }
     m->graph_on = graph_enabled();
@@ -1443,6 +1379,20 @@ extern "C" int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void*), v
     DCV_REQUIRE(m, "dcv_mlp_set_upper_grads_callback: null");
     m->upper_cb = fn;
     m->upper_cb_user = user;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_set_rank(dcv_mlp* m, int32_t rank) {
+    DCV_REQUIRE(m && rank >= 0, "dcv_mlp_set_rank: bad arguments");
+    m->drop_rank = (uint32_t)rank;
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_layer_output(dcv_mlp* m, int32_t layer, int64_t rows, float* out_d, void* stream) {
+    DCV_REQUIRE(m && out_d && layer >= 0 && layer < m->L && rows >= 1 && rows <= m->rows_cap, "dcv_mlp_layer_output: bad arguments");
+    const LayerPlan& p = m->layers[layer];
+    DCV_CHECK_HIP(hipMemcpy2DAsync(out_d, (size_t)p.out * sizeof(float), p.H, (size_t)p.ldh * sizeof(float), (size_t)p.out * sizeof(float),
+                                   (size_t)rows, hipMemcpyDeviceToDevice, as_stream(stream)));
     return DCV_OK;
 }
 
@@ -1986,6 +1936,43 @@ static int apply_impl(dcv_mlp* m, void* stream) {
     return DCV_OK;
 }
 
+// One-GPU autoencoder step as ONE fused launch (+ the gradient reduction with the optimiser update) when the network
+// fits in LDS (snet.hip); 1 = not applicable: the caller runs the layer-by-layer path.
+static int snet_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int32_t train, void* stream) {
+    if (m->desc.model != DCV_MODEL_AE || m->any_drop || (m->snet_tried && m->snet == nullptr)) return 1;
+    if (!(Xn_d && batch >= 1 && batch <= m->desc.max_batch && ld >= m->desc.dims[0] && m->log && m->log_cap > 0)) return 1;   // the general path reports it
+    hipStream_t s = as_stream(stream);
+    const RowMap rm = RowMap{idx_d, row0, 0, 0};
+    ReduceArgsView v;
+    prof_mark(m, 0, 0, 0, s);   // profiling: the fused launch is reported under both layer-0 classes (forward, weight gradient)
+    prof_mark(m, 0, 1, 0, s);
+    int rc = snet_ae_step(m, Xn_d, ld, rm, batch, batch, train, &v, s);
+    if (rc) return rc;
+    prof_mark(m, 0, 0, 1, s);
+    prof_mark(m, 0, 1, 1, s);
+    if (train && m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
+    m->fwd_train = train != 0;
+    if (m->fwd_train) m->cur_step = m->drop_step++;
+    m->head_done = false;
+    m->last_batch = batch;
+    if (!train) return DCV_OK;
+    ReduceArgs ra;
+    ra.L = m->L;
+    for (int l = 0; l < m->L; ++l) {
+        const LayerPlan& p = m->layers[l];
+        ReduceDesc& rd = ra.l[l];
+        rd.slab = v.slab[l];
+        rd.bpart = v.bpart[l];
+        rd.w_off = p.w_off;
+        rd.b_off = p.b_off;
+        rd.w_count = (int64_t)p.out * p.in;
+        rd.out = p.out;
+        rd.splits = v.splits[l];
+        rd.bblocks = v.bblocks[l];
+    }
+    return launch_reduce(m, ra, 0, m->L, true, next_opt_args(m), s);
+}
+
 extern "C" int dcv_mlp_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                                int32_t train, void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_forward: null");
@@ -2011,7 +1998,9 @@ extern "C" int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, con
                                   void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_train_step: null");
     return run_graphed(m, 0, as_stream(stream), [&] {
-        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 1, stream, 1);
+        int rc = snet_step(m, Xn_d, ld, idx_d, row0, batch, 1, stream);
+        if (rc != 1) return rc;
+        rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 1, stream, 1);
         if (rc) return rc;
         return backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 1, stream, true);   // reduction + optimiser update in one launch
     });
@@ -2021,10 +2010,68 @@ extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, cons
                                  void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_eval_step: null");
     return run_graphed(m, 3, as_stream(stream), [&] {
-        int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 0, stream, 2);
+        int rc = snet_step(m, Xn_d, ld, idx_d, row0, batch, 0, stream);
+        if (rc != 1) return rc;
+        rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, 0, stream, 2);
         if (rc) return rc;
         return backward_impl(m, Xn_d, ld, idx_d, row0, batch, batch, 0, stream);
     });
+}
+
+// ---- data-parallel step: the whole sequence behind one entry point, the collectives through a host callback
+namespace {
+struct DpTrampoline {
+    dcv_mlp* m;
+    dcv_allreduce_fn fn;
+    void* user;
+    int rc;
+};
+void dp_upper_cb(void* p) {
+    DpTrampoline* t = static_cast<DpTrampoline*>(p);
+    const int64_t off = t->m->layers[1].w_off;
+    t->rc = t->fn(t->user, t->m->grads + off, t->m->n_params - off, DCV_DTYPE_F32, DCV_DP_UPPER_START);
+}
+}  // namespace
+
+extern "C" int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                               int64_t global_batch, int32_t train, int32_t overlap, dcv_allreduce_fn fn, void* user, void* stream) {
+    DCV_REQUIRE(m && fn, "dcv_mlp_dp_step: null argument");
+    int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, train, stream, 0);
+    if (rc) return rc;
+    if (fn(user, m->stats, m->stats_len, DCV_DTYPE_F64, DCV_DP_STATS) != 0) {
+        set_error("dcv_mlp_dp_step: the all-reduce callback failed (statistics)");
+        return DCV_ECALLBACK;
+    }
+    if (!train) return backward_impl(m, Xn_d, ld, idx_d, row0, batch, global_batch, 0, stream);
+    if (overlap && m->L > 1) {
+        // the gradients of layers 1.. are reduced and handed to the callback before the layer-0 weight gradient is
+        // enqueued (dcv_mlp_set_upper_grads_callback): their exchange runs under the largest product of the step
+        DpTrampoline t{m, fn, user, 0};
+        void (*keep_cb)(void*) = m->upper_cb;
+        void* keep_user = m->upper_cb_user;
+        m->upper_cb = dp_upper_cb;
+        m->upper_cb_user = &t;
+        rc = backward_impl(m, Xn_d, ld, idx_d, row0, batch, global_batch, 1, stream);
+        m->upper_cb = keep_cb;
+        m->upper_cb_user = keep_user;
+        if (rc) return rc;
+        if (t.rc != 0 || fn(user, m->grads, m->layers[1].w_off, DCV_DTYPE_F32, DCV_DP_GRADS) != 0 ||
+            fn(user, nullptr, 0, DCV_DTYPE_F32, DCV_DP_WAIT) != 0) {
+            set_error("dcv_mlp_dp_step: the all-reduce callback failed (gradients)");
+            return DCV_ECALLBACK;
+        }
+    } else {
+        void (*keep_cb)(void*) = m->upper_cb;
+        m->upper_cb = nullptr;
+        rc = backward_impl(m, Xn_d, ld, idx_d, row0, batch, global_batch, 1, stream);
+        m->upper_cb = keep_cb;
+        if (rc) return rc;
+        if (fn(user, m->grads, m->n_params, DCV_DTYPE_F32, DCV_DP_GRADS) != 0) {
+            set_error("dcv_mlp_dp_step: the all-reduce callback failed (gradients)");
+            return DCV_ECALLBACK;
+        }
+    }
+    return apply_impl(m, stream);
 }
 
 extern "C" int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t ld, const float* tmean_d, const float* tevecs_d,

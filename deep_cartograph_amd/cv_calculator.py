@@ -971,6 +971,7 @@ class NonLinear(CVCalculator):
                               tica_reg=float(self.configuration.get("tica_regularization", 1e-6)), dropout=drops, seed=seed, device=dev,
                               **self._engine_optimizer_kwargs(opt_name, opt_kw))
         self.engine.set_linears(linears)
+        self.engine.set_rank(self.comm.rank)   # data-parallel ranks hold the same seed: independent dropout masks per rank
         if self.model_kind == "ae":
             self.engine.set_feature_range(self.features_norm_range)
         self._stats_view = self.engine.stats_view()

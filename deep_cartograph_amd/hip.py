@@ -198,6 +198,8 @@ def kmeanspp_update(P: torch.Tensor, centre: torch.Tensor, closest: torch.Tensor
     _check_matrix(P, torch.float64)
     lib = _lib.load()
     n, d = P.shape
+    if n == 0:   # an empty shard of a frame-sharded run contributes nothing
+        return torch.zeros(1, dtype=torch.float64, device=P.device)
     pot = torch.empty(1, dtype=torch.float64, device=P.device)
     ws = _ws(lib.dcv_kmeanspp_workspace(n, 1), P.device)
     check(lib.dcv_kmeanspp_update(_ptr(P), n, d, _ptr(offset), _ptr(centre), 1 if first else 0, _ptr(closest), _ptr(pot), _ptr(ws), ws.numel(),
@@ -212,6 +214,8 @@ def kmeanspp_potentials(P: torch.Tensor, cand: torch.Tensor, closest: torch.Tens
     lib = _lib.load()
     n, d = P.shape
     t = cand.shape[0]
+    if n == 0:
+        return torch.zeros(t, dtype=torch.float64, device=P.device)
     pot = torch.empty(t, dtype=torch.float64, device=P.device)
     ws = _ws(lib.dcv_kmeanspp_workspace(n, t), P.device)
     check(lib.dcv_kmeanspp_potentials(_ptr(P), n, d, _ptr(offset), _ptr(cand.contiguous()), t, _ptr(closest), _ptr(pot), _ptr(ws), ws.numel(),
@@ -366,6 +370,10 @@ class Mlp:
         self.log_width = self.lib.dcv_mlp_log_width(self.h)
         self.stats_len = self.lib.dcv_mlp_stats_len(self.h)
         self._log_cap = 0
+        self._dp = None            # state of data_parallel_step (callback thunk, tensor views of the library's buffers)
+        self._upper_thunk = None   # ctypes thunk of backward(on_upper_grads=...)
+        self._upper_fn = None
+        self._upper_err = None
 
     def close(self):
         if getattr(self, "h", None):
@@ -468,15 +476,28 @@ class Mlp:
 
         batch = int(batch if batch is not None else idx.numel())
         gb = int(global_batch if global_batch is not None else batch)
-        cb = None
-        if on_upper_grads is not None and train and self.L > 1:
-            cb = C.CFUNCTYPE(None, C.c_void_p)(lambda _u: on_upper_grads())
-            check(self.lib.dcv_mlp_set_upper_grads_callback(self.h, C.cast(cb, C.c_void_p), None), "dcv_mlp_set_upper_grads_callback")
+        use_cb = on_upper_grads is not None and train and self.L > 1
+        if use_cb:
+            if self._upper_thunk is None:   # one thunk per engine; the Python callable of the current call sits in a cell
+
+                def _tramp(_u):
+                    try:
+                        self._upper_fn()
+                    except BaseException as e:   # ctypes would print and swallow it
+                        self._upper_err = e
+
+                self._upper_thunk = C.CFUNCTYPE(None, C.c_void_p)(_tramp)
+            self._upper_fn, self._upper_err = on_upper_grads, None
+            check(self.lib.dcv_mlp_set_upper_grads_callback(self.h, C.cast(self._upper_thunk, C.c_void_p), None), "dcv_mlp_set_upper_grads_callback")
         try:
             check(self.lib.dcv_mlp_backward(self.h, *self._args(Xn, idx, row0, batch), gb, 1 if train else 0, _stream()), "dcv_mlp_backward")
         finally:
-            if cb is not None:
+            if use_cb:
                 check(self.lib.dcv_mlp_set_upper_grads_callback(self.h, None, None), "dcv_mlp_set_upper_grads_callback")
+                self._upper_fn = None
+        if use_cb and self._upper_err is not None:
+            e, self._upper_err = self._upper_err, None
+            raise e
 
     def upper_grads_view(self) -> torch.Tensor:
         """Gradients of layers 1.. (the tail of the flat buffer)."""
@@ -486,34 +507,63 @@ class Mlp:
         return self.grads_view()[: self.offsets[1][0]] if self.L > 1 else self.grads_view()
 
     def data_parallel_step(self, Xn, dist, global_batch, idx=None, row0=0, batch=None, train=True, group=None):
-        """One synchronous data-parallel step over `dist` (torch.distributed): forward, all-reduce of the batch
-        statistics, backward with the gradient all-reduce of the upper layers started under the layer-0 weight
-        gradient, all-reduce of the layer-0 part, optimiser update."""
-        self.forward(Xn, idx=idx, row0=row0, batch=batch, train=train)
-        dist.all_reduce(self.stats_view(), op=dist.ReduceOp.SUM, group=group)
-        if not train:
-            self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=False)
-            return
+        """One synchronous data-parallel step over `dist` (torch.distributed) as ONE library call (dcv_mlp_dp_step):
+        forward, all-reduce of the batch statistics, backward, all-reduce of the gradient buffer (from 32 768 rows per
+        rank up in two pieces, the upper layers' started under the layer-0 weight gradient; DCV_DP_OVERLAP=0|1 forces
+        either form), optimiser update.  The collectives run in a host callback; an exception raised there (an RCCL
+        error, say) aborts the step inside the library and is re-raised here -- never swallowed."""
+        import ctypes as C
+
         rows = int(batch if batch is not None else idx.numel())
         env = os.environ.get("DCV_DP_OVERLAP")
         # The two-piece form pays one more collective launch (~15-20 us of latency at these message sizes) to hide the
         # upper layers' all-reduce under the layer-0 weight gradient: worth it only when that product outlasts a
-        # collective -- not at a few thousand rows per rank (8192-pair global batch over 1-8 ranks), where the whole
-        # gradient buffer goes out as one all-reduce.
+        # collective -- not at a few thousand rows per rank (8192-pair global batch over 1-8 ranks).
         overlap = (rows >= 32768) if env is None else env == "1"
-        upper, lower = self.upper_grads_view(), self.layer0_grads_view()
-        if not overlap or not upper.numel():
-            self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=True)
-            dist.all_reduce(self.grads_view(), op=dist.ReduceOp.SUM, group=group)
-            self.apply()
-            return
-        pending = []
-        self.backward(Xn, idx=idx, row0=row0, batch=batch, global_batch=global_batch, train=True,
-                      on_upper_grads=lambda: pending.append(dist.all_reduce(upper, op=dist.ReduceOp.SUM, group=group, async_op=True)))
-        dist.all_reduce(lower, op=dist.ReduceOp.SUM, group=group)
-        for w in pending:
-            w.wait()
-        self.apply()
+        st = self._dp
+        if st is None:
+            st = self._dp = {"views": {}, "pending": [], "error": None, "dist": None, "group": None}
+
+            def _cb(_user, buf, count, dtype, phase):
+                try:
+                    if phase == 3:   # DCV_DP_WAIT
+                        for w in st["pending"]:
+                            w.wait()
+                        st["pending"].clear()
+                        return 0
+                    key = (int(buf), int(count), int(dtype))
+                    t = st["views"].get(key)
+                    if t is None:
+                        t = st["views"][key] = self._flat_view(buf, int(count), torch.float64 if dtype == 1 else torch.float32)
+                    d = st["dist"]
+                    if phase == 2:   # DCV_DP_UPPER_START
+                        st["pending"].append(d.all_reduce(t, op=d.ReduceOp.SUM, group=st["group"], async_op=True))
+                    else:
+                        d.all_reduce(t, op=d.ReduceOp.SUM, group=st["group"])
+                    return 0
+                except BaseException as e:   # ctypes would print and swallow it: stash, fail the step, re-raise outside
+                    st["error"] = e
+                    return 1
+
+            st["thunk"] = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32)(_cb)
+        st["dist"], st["group"], st["error"] = dist, group, None
+        st["pending"].clear()
+        rc = self.lib.dcv_mlp_dp_step(self.h, *self._args(Xn, idx, row0, rows), int(global_batch), 1 if train else 0, 1 if overlap else 0,
+                                      C.cast(st["thunk"], C.c_void_p), None, _stream())
+        if st["error"] is not None:
+            err, st["error"] = st["error"], None
+            raise err
+        check(rc, "dcv_mlp_dp_step")
+
+    def set_rank(self, rank: int):
+        """Rank of this engine in a data-parallel run (independent dropout masks per rank)."""
+        check(self.lib.dcv_mlp_set_rank(self.h, int(rank)), "dcv_mlp_set_rank")
+
+    def layer_output(self, layer: int, rows: int) -> torch.Tensor:
+        """Post-activation output of Linear `layer` in the last forward (test hook)."""
+        out = torch.empty(int(rows), self.dims[layer + 1], dtype=torch.float32, device=self.device)
+        check(self.lib.dcv_mlp_layer_output(self.h, int(layer), int(rows), _ptr(out), _stream()), "dcv_mlp_layer_output")
+        return out
 
     def apply(self):
         check(self.lib.dcv_mlp_apply(self.h, _stream()), "dcv_mlp_apply")

@@ -167,8 +167,6 @@ def kmeans_clustering(feature_matrix: np.ndarray, num_clusters: int, n_init: int
         init = None
     if not (1 <= num_clusters <= 64) or pts.d > 16:
         raise NotImplementedError(f"the HIP k-means kernel supports k <= 64, d <= 16 (got k={num_clusters}, d={pts.d})")
-    if init is None and pts.d > 8:
-        raise NotImplementedError(f"the HIP k-means++ seeding passes support d <= 8 (got d={pts.d}); pass initial centroids")
     logger.debug(f"Number of clusters: {num_clusters}")
     best = None
     for _ in range(n_init):

@@ -37,6 +37,7 @@ extern "C" {
 #define DCV_EHIP (-2)    /* HIP runtime error */
 #define DCV_ENOMEM (-3)  /* workspace too small / allocation failed */
 #define DCV_ESTATE (-4)  /* call order violated */
+#define DCV_ECALLBACK (-5) /* a host callback of the caller reported failure */
 
 #define DCV_ABI_VERSION 2
 
@@ -220,6 +221,32 @@ int dcv_mlp_apply(dcv_mlp* m, void* stream);
  * the exchange runs under the layer-0 product; the layer-0 part [0, dcv_mlp_param_offset(m, 1, 0)) is reduced when
  * the call returns.  fn = NULL restores the single reduction. */
 int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void* user), void* user);
+/* One data-parallel step behind ONE entry point: forward, all-reduce of the batch statistics, backward, all-reduce of
+ * the gradient buffer, optimiser update -- the sequence a caller would otherwise drive phase by phase (five calls across
+ * the language boundary per step).  The collectives are the caller's: fn(user, buf_d, count, dtype, phase) must make the
+ * SUM over all ranks of the `count` elements at buf_d (device memory, dtype DCV_DTYPE_F32 / DCV_DTYPE_F64) visible to work
+ * that is enqueued on `stream` after it returns (an RCCL / torch.distributed all-reduce ordered against that stream does).
+ * phase says what is being exchanged: DCV_DP_STATS (dcv_mlp_stats), DCV_DP_GRADS (the gradient buffer, or its layer-0
+ * part), and -- with overlap != 0 and more than one layer -- DCV_DP_UPPER_START for the gradients of layers 1.., handed
+ * over BEFORE the layer-0 weight gradient is enqueued: that exchange may complete asynchronously under it and is
+ * awaited by the closing call fn(user, NULL, 0, DCV_DTYPE_F32, DCV_DP_WAIT).  fn returns 0, or nonzero to abort the step
+ * (dcv_mlp_dp_step then returns DCV_ECALLBACK).  train = 0: evaluation step (statistics exchanged, loss logged).
+ * Replaces, on the reference side, lightning's DDP hooks around cv_calculator.py:1515-1524 (the reference itself is
+ * single-process). */
+#define DCV_DTYPE_F32 0
+#define DCV_DTYPE_F64 1
+#define DCV_DP_STATS 0
+#define DCV_DP_GRADS 1
+#define DCV_DP_UPPER_START 2
+#define DCV_DP_WAIT 3
+typedef int (*dcv_allreduce_fn)(void* user, void* buf_d, int64_t count, int32_t dtype, int32_t phase);
+int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
+                    int64_t global_batch, int32_t train, int32_t overlap, dcv_allreduce_fn fn, void* user, void* stream);
+/* Rank of this engine in a data-parallel run: mixed into the key of the dropout counters, so that ranks holding the same
+ * seed mask their local rows independently (default 0). */
+int dcv_mlp_set_rank(dcv_mlp* m, int32_t rank);
+/* Test hook: post-activation output of Linear `layer` in the last forward (rows x dims[layer + 1] floats, dense). */
+int dcv_mlp_layer_output(dcv_mlp* m, int32_t layer, int64_t rows, float* out_d, void* stream);
 /* Convenience for one GPU: forward + backward(train=1) + apply. */
 int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
                        int32_t batch, void* stream);

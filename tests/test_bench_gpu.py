@@ -1,0 +1,42 @@
+"""bench.py's multi-rank control flow, rehearsed on the one-GPU box: two ranks share the GPU, torch.distributed runs on
+gloo (device tensors staged through the host) -- the branch a driver takes on an 8-GPU node (shard seeds, statistics
+all-reduce, dcv_mlp_dp_step with its all-reduce callback, MAX of the elapsed times, rank-0 JSON line) has then executed
+once before it meets RCCL."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_world2_control_flow():
+    port = _free_port()
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "400000", "--batch", "4096",
+            "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--large-batch", "0", "--other-mode-steps", "0", "--profile-every", "2"]
+    procs = []
+    for rank in (0, 1):   # fresh child processes: nothing here has touched the GPU on their behalf
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    assert outs[1][0].strip() == ""                      # only rank 0 prints
+    line = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "strong"
+    assert line["metric"].startswith("Deep-TICA training frames/sec")
+    assert line["config"]["parallelism"] == "frame-shard dp2" and line["config"]["global_batch"] == 4096
+    assert line["value"] > 0 and abs(line["value"] - 6 * 4096 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]
+    assert line["roofline"] is not None and line["roofline"]["rows_per_launch"] == 2048 + 10
+    assert line["loss_first"] is not None and -4.0 <= line["loss_last_train"] <= 0.0   # -sum(eig^2) of a d = 4 TICA
+    assert "cpu_baseline" not in line

@@ -100,20 +100,21 @@ def test_handoff_isa_order(tmp_path):
         for i, s in enumerate(ins):
             if not (re.match(r"global_atomic_add\s", s) and " sc0" in s):   # a returning add = a ticket
                 continue
-            # ---- producer side: backwards to the last payload store
+            # ---- producer side: ... stores ; s_waitcnt vmcnt(0) ; s_barrier ; (no store) ; ticket -- and the payload
+            # (the partials handed over in-launch) written with sc1 stores somewhere ahead of that wait.  Plain stores
+            # ahead of the wait are outputs for LATER launches (gradient partials of the fused small-network step).
             j = i - 1
-            saw_barrier = saw_wait_before_barrier = False
-            while j >= 0 and not is_store(ins[j]):
-                if ins[j].startswith("s_barrier"):
-                    saw_barrier = True
-                    saw_wait_before_barrier = False   # a wait must sit between the store and THIS (earlier) barrier
-                if ins[j].startswith("s_waitcnt") and "vmcnt(0)" in ins[j] and saw_barrier:
-                    saw_wait_before_barrier = True
+            while j >= 0 and not ins[j].startswith("s_barrier"):
+                assert not is_store(ins[j]), f"{name}: a store sits between the barrier and the ticket: {ins[j]}"
                 j -= 1
-            assert j >= 0, f"{name}: ticket without a payload store"
-            assert " sc1" in ins[j], f"{name}: payload store is not write-through: {ins[j]}"
-            assert saw_barrier, f"{name}: no workgroup barrier between the payload store and the ticket"
-            assert saw_wait_before_barrier, f"{name}: no s_waitcnt vmcnt(0) between the last payload store and the barrier in front of the ticket"
+            assert j >= 0, f"{name}: no workgroup barrier in front of the ticket"
+            j -= 1
+            while j >= 0 and not (ins[j].startswith("s_waitcnt") and "vmcnt(0)" in ins[j]):
+                assert not is_store(ins[j]) and not ins[j].startswith("s_barrier"), \
+                    f"{name}: no s_waitcnt vmcnt(0) between the last store and the barrier in front of the ticket ({ins[j]})"
+                j -= 1
+            assert j >= 0, f"{name}: no s_waitcnt vmcnt(0) in front of the ticket's barrier"
+            assert any(is_store(x) and " sc1" in x for x in ins[:j]), f"{name}: no write-through (sc1) payload store ahead of the ticket"
             # ---- consumer side: forwards to the first sc1 load of the last arriver
             k = i + 1
             inv = wait_after_inv = barrier_after = False

@@ -129,6 +129,79 @@ def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather, m
     print(f"{mode} {dims} batch {batch}: worst gradient deviation from float64 = {worst:.2e} of the largest entry")
 
 
+@pytest.mark.parametrize("mode", ["split", "native"])
+def test_contract_batch_leaky_relu_step_kink_aware(mode):
+    """The bench's own configuration -- 512-256-128-4, leaky-ReLU, 8192 contiguous pairs + lag 10 -- against float64.
+    Among the three million hidden units of such a batch a few pre-activations sit within float32 rounding of the kink,
+    and one flipped slope (1 vs 0.01) moves a gradient entry by 1e-4 of the largest one in ANY float32 implementation.
+    Kink-aware criterion: (i) the engine's slope decisions (sign of its stored activations) may differ from the float64
+    ones only where the float64 pre-activation is within 1e-5 of zero; (ii) given the engine's slope pattern -- the
+    network is then piecewise linear with that pattern fixed -- every gradient tensor, the statistics and the loss must
+    agree with the float64 evaluation to the tolerances of test_deeptica_step_matches_autograd."""
+    from deep_cartograph_amd import hip
+
+    dims, lag, batch, row0 = [512, 256, 128, 4], 10, 8192, 7
+    acts = ["leaky_relu", "leaky_relu", None]
+    Xn, _, _ = normalized(ar_features(8300, dims[0], 31))
+    torch.manual_seed(6)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    prev = hip.get_gemm_mode()
+    hip.set_gemm_mode(mode)
+    R = batch + lag
+    try:
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+        push_params(eng, linears_of(ref.nn))
+        Xd = torch.from_numpy(Xn).cuda()
+        eng.reset_log(2)
+        eng.forward(Xd, row0=row0, batch=batch)
+        stats = eng.stats_view().cpu().numpy()
+        H = [eng.layer_output(l, R).cpu().numpy() for l in (0, 1)]
+        eng.backward(Xd, row0=row0, batch=batch)
+        g = eng.grads_view().cpu().numpy()
+        rec = eng.read_log()[0]
+        offsets = list(eng.offsets)
+        eng.close()
+    finally:
+        hip.set_gemm_mode(prev)
+    W = [l.weight.detach().double().clone().requires_grad_(True) for l in linears_of(ref.nn)]
+    b = [l.bias.detach().double().clone().requires_grad_(True) for l in linears_of(ref.nn)]
+    x = torch.from_numpy(Xn[row0:row0 + R]).double()
+    h, flips = x, []
+    for l in (0, 1):
+        z = h @ W[l].T + b[l]
+        m_eng = torch.from_numpy(H[l] > 0)
+        differ = m_eng != (z.detach() > 0)
+        flips.append(int(differ.sum()))
+        if differ.any():   # (i): only units within float32 rounding of the kink
+            assert float(z.detach().abs()[differ].max()) < 1e-5, f"layer {l}: slope decision differs away from the kink"
+        h = z * torch.where(m_eng, 1.0, 0.01).double()   # (ii): the engine's slope pattern, fixed
+    f = h @ W[2].T + b[2]
+    f_t, f_l = f[:batch], f[lag:lag + batch]
+    evals, _, _ = onn.batch_tica(f_t, f_l, 1e-6)
+    loss = onn.deeptica_loss(evals)
+    loss.backward()
+    d = dims[-1]
+    np.testing.assert_allclose(stats[:d], f_t.detach().sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[2 * d:2 * d + d * d].reshape(d, d), (f_t.T @ f_t).detach().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(stats[2 * d + d * d:].reshape(d, d), (f_t.T @ f_l).detach().numpy(), rtol=2e-5, atol=2e-5)
+    assert abs(rec[0] - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    worst = 0.0
+    for l in range(3):
+        wo, bo = offsets[l]
+        gw, gb = W[l].grad.numpy(), b[l].grad.numpy()
+        ew = rel_err(g[wo:wo + gw.size].reshape(gw.shape), gw)
+        worst = max(worst, ew)
+        assert ew < 2e-5, f"layer {l} weight: {ew:.2e}"
+        if l < 2:
+            eb = rel_err(g[bo:bo + gb.size], gb)
+            worst = max(worst, eb)
+            assert eb < 2e-5, f"layer {l} bias: {eb:.2e}"
+        else:
+            assert np.max(np.abs(g[bo:bo + gb.size])) < 2e-5 * max(1.0, np.max(np.abs(gw))), "last bias"
+    print(f"{mode} contract batch, leaky-ReLU: slope decisions differing from float64 (all within 1e-5 of the kink): {flips}; "
+          f"worst gradient deviation from float64 given the slope pattern = {worst:.2e} of the largest entry")
+
+
 def test_contract_batch_step_is_reproducible():
     """The contraction-split tail tile (8202 rows: 512 regular + 32 tail-chunk workgroups per product) adds its chunks up in
     chunk order whatever the arrival order: statistics, loss and every gradient of repeated steps on the same weights are
@@ -196,6 +269,9 @@ def test_deeptica_row_sharing_equivalence():
     eng.close()
 
 
+DT_TRAIN_TOL = {"loss": 2e-3, "w": 3e-4, "b": 3e-4}   # provisional: 3 x the measured deviations
+
+
 def test_deeptica_training_matches_oracle():
     from deep_cartograph_amd import hip
 
@@ -224,11 +300,15 @@ def test_deeptica_training_matches_oracle():
             eng.train_step(Xd, idx=b.cuda())
     log = eng.read_log()
     assert log.shape[0] == len(ref_losses)
-    np.testing.assert_allclose(log[:, 0], ref_losses, rtol=2e-3, atol=2e-4)
+    dev_loss = float(np.max(np.abs(log[:, 0] - np.asarray(ref_losses)) / np.maximum(np.abs(ref_losses), 0.1)))
+    dev_w = max(float(np.max(np.abs(w - lin.weight.detach().numpy()))) for (w, _), lin in zip(eng.get_linears(), lins))
+    dev_b = max(float(np.max(np.abs(b - lin.bias.detach().numpy()))) for (_, b), lin in zip(eng.get_linears()[:-1], lins[:-1]))
+    print(f"deep-tica training vs float32 oracle after {len(ref_losses)} steps: loss {dev_loss:.2e} (relative), weights {dev_w:.2e}, hidden biases {dev_b:.2e}")
+    np.testing.assert_allclose(log[:, 0], ref_losses, rtol=DT_TRAIN_TOL["loss"], atol=DT_TRAIN_TOL["loss"] * 0.1)
     for l, ((w, b), lin) in enumerate(zip(eng.get_linears(), lins)):
-        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=3e-4)
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=DT_TRAIN_TOL["w"])
         if l < len(lins) - 1:  # last bias: zero exact gradient, Adam amplifies rounding noise on both sides
-            np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=3e-4)
+            np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=DT_TRAIN_TOL["b"])
     # validation pass: eval steps log the loss and leave the parameters alone
     before = eng.get_linears()
     eng.reset_log(8)

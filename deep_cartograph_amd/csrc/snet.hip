@@ -22,8 +22,13 @@ namespace dcv {
 
 typedef float sv4f __attribute__((ext_vector_type(4)));
 
+constexpr int kSnetThreads = 512;   // 8 waves: two per SIMD, one hides the other's LDS and MFMA latency
+constexpr int kSnetWaves = kSnetThreads / 64;
+
 struct SnetLayer {
     int in, out, pin, pout, act;
+    int nk_in, nk_out;          // pin / 16, pout / 16
+    int u4_begin, c4_shift;     // staging: first 16-byte unit of this layer's weight image in the flat unit space; log2(pin / 4)
     int64_t w_off, b_off;       // flat parameter buffer
     int lw, lb, pws;            // LDS float offsets of the weight image [pout][pws] and the bias [pout]; pws = pin + 4
     int64_t pw_off, pb_off;     // gradient partials: part + pw_off + wg * out * in ; part + pb_off + wg * out
@@ -31,9 +36,12 @@ struct SnetLayer {
 struct SnetArgs {
     SnetLayer l[DCV_MAX_LAYERS];
     int L;
+    const int2* stage_tab;        // staging table: per 16-byte unit of the LDS image {source element offset into params or -1,
+                                  // LDS float offset | valid elements << 20 | 16-byte load legal << 24}
+    int stage_n;
     int lh[DCV_MAX_LAYERS + 1];   // LDS float offset of H_l [TR][ps_l]   (H_0 = the input tile)
-    int ps[DCV_MAX_LAYERS + 1];   // row stride of H_l = round_up(dims[l], 16) + 4
-    int lred;                     // LDS float offset of the reduction scratch (256 doubles)
+    int ps[DCV_MAX_LAYERS + 1];   // row stride of H_l = padded width + 4
+    int lred;                     // LDS float offset of the reduction scratch (kSnetThreads doubles)
     const float* params;
     const float* Xn;
     int64_t ld;
@@ -50,99 +58,213 @@ struct SnetArgs {
     double* log;
     int* log_count;
     int log_cap, log_width;
+    unsigned long long* stamps;   // diagnostic (dcv_debug_snet_stamps): s_memrealtime of workgroup 0 at the phase boundaries, or null
 };
+#define SNET_STAMP(k)                                                                          \
+    do {                                                                                        \
+        if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[k] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
 
 __device__ __forceinline__ sv4f mfma4(float a, float b, sv4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-// D[r][c] (16 rows of row group rg, 16 columns of column tile ct) = sum_k Hin[r][k] W[c][k], k < pin
-__device__ __forceinline__ sv4f snet_fwd_tile(const float* Hin, int psin, const float* W, int pws, int rg, int ct, int pin, int lane) {
-    sv4f acc = {0.f, 0.f, 0.f, 0.f};
-    const float* ap = Hin + (rg * 16 + (lane & 15)) * psin + 4 * (lane >> 4);
-    const float* bp = W + (ct * 16 + (lane & 15)) * pws + 4 * (lane >> 4);
-#pragma unroll 2
-    for (int k0 = 0; k0 < pin; k0 += 16) {
-        const sv4f a = *reinterpret_cast<const sv4f*>(ap + k0);
-        const sv4f b = *reinterpret_cast<const sv4f*>(bp + k0);
-        acc = mfma4(a[0], b[0], acc);
-        acc = mfma4(a[1], b[1], acc);
-        acc = mfma4(a[2], b[2], acc);
-        acc = mfma4(a[3], b[3], acc);
+// Contraction lengths are compile-time (NK chunks of 16; the plan pads every width to 16 * 2^j): the fragment reads of
+// a tile are issued back to back, the MFMAs run in up to four independent accumulator chains, no branch in between.
+// (With run-time trip counts hipcc emitted ds_read -> s_waitcnt lgkmcnt(0) -> 4 dependent MFMAs -> branch per chunk:
+// 1.2 us of fixed cost per layer, 51 us per fused step.)
+template <int NK>
+struct SnetFrags {
+    sv4f f[NK];
+    __device__ __forceinline__ void load(const float* p) {   // p: this lane's row, offset 4 * q; chunk j at p + 16 j
+#pragma unroll
+        for (int j = 0; j < NK; ++j) f[j] = *reinterpret_cast<const sv4f*>(p + 16 * j);
     }
-    return acc;
+};
+template <int NK>
+__device__ __forceinline__ sv4f snet_chain_sum(sv4f (&acc)[(NK < 4 ? NK : 4)]) {
+    constexpr int C = NK < 4 ? NK : 4;
+    sv4f r = acc[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) r += acc[c];
+    return r;
 }
-// D[r][i] = sum_o dZ[r][o] W[o][i], o < pout  (input gradient before the activation derivative)
-__device__ __forceinline__ sv4f snet_dgrad_tile(const float* dZ, int psz, const float* W, int pws, int rg, int it, int pout, int lane) {
-    sv4f acc = {0.f, 0.f, 0.f, 0.f};
-    const int q = lane >> 4, n = lane & 15;
-    const float* ap = dZ + (rg * 16 + n) * psz + 4 * q;
-    const float* bp = W + (4 * q) * pws + it * 16 + n;
-#pragma unroll 2
-    for (int k0 = 0; k0 < pout; k0 += 16) {
-        const sv4f a = *reinterpret_cast<const sv4f*>(ap + k0);
-        const float* b = bp + k0 * pws;
-        acc = mfma4(a[0], b[0], acc);
-        acc = mfma4(a[1], b[pws], acc);
-        acc = mfma4(a[2], b[2 * pws], acc);
-        acc = mfma4(a[3], b[3 * pws], acc);
+// D[r][c] = sum_k A[r][k] W[c][k]  (forward: A = activations of the wave's 16 rows, W row-major [out][in])
+template <int NK>
+__device__ __forceinline__ sv4f snet_fwd_tile(const SnetFrags<NK>& A, const float* bp) {
+    constexpr int C = NK < 4 ? NK : 4;
+    SnetFrags<NK> B;
+    B.load(bp);
+    sv4f acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = sv4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[j % C] = mfma4(A.f[j][s], B.f[j][s], acc[j % C]);
     }
-    return acc;
+    return snet_chain_sum<NK>(acc);
+}
+// D[r][i] = sum_o dZ[r][o] W[o][i]  (input gradient: A = dZ rows, B = a column block of W read down the rows)
+template <int NK>
+__device__ __forceinline__ sv4f snet_dgrad_tile(const SnetFrags<NK>& A, const float* bp, int pws) {
+    constexpr int C = NK < 4 ? NK : 4;
+    float b[NK][4];
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[j][s] = bp[(16 * j + s) * pws];
+    sv4f acc[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[c] = sv4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[j % C] = mfma4(A.f[j][s], b[j][s], acc[j % C]);
+    }
+    return snet_chain_sum<NK>(acc);
 }
 // D[o][i] = sum_r dZ[r][o] Hin[r][i], r < TR  (weight gradient of the tile)
 template <int TR>
-__device__ __forceinline__ sv4f snet_wgrad_tile(const float* dZ, int psz, const float* Hin, int psh, int ot, int it, int lane) {
-    sv4f acc = {0.f, 0.f, 0.f, 0.f};
-    const int q = lane >> 4, n = lane & 15;
-    const float* ap = dZ + q * psz + ot * 16 + n;
-    const float* bp = Hin + q * psh + it * 16 + n;
+__device__ __forceinline__ sv4f snet_wgrad_tile(const float* ap, int psz, const float* bp, int psh) {
+    float av[TR / 4], bv[TR / 4];
 #pragma unroll
-    for (int s = 0; s < TR / 4; ++s) acc = mfma4(ap[4 * s * psz], bp[4 * s * psh], acc);
-    return acc;
+    for (int s = 0; s < TR / 4; ++s) {
+        av[s] = ap[4 * s * psz];
+        bv[s] = bp[4 * s * psh];
+    }
+    sv4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < TR / 4; s += 2) {
+        acc0 = mfma4(av[s], bv[s], acc0);
+        acc1 = mfma4(av[s + 1], bv[s + 1], acc1);
+    }
+    return acc0 + acc1;
 }
 
-constexpr int kSnetMaxTiles = 8;   // column tiles of a layer per wave: widths up to 16 * CG * 8
+// activation with the switch outside the element loop
+__device__ __forceinline__ sv4f snet_act4(int act, sv4f z) {
+    sv4f h;
+    switch (act) {
+        case DCV_ACT_NONE: h = z; break;
+        case DCV_ACT_LEAKY_RELU:
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[v] = z[v] > 0.f ? z[v] : 0.01f * z[v];
+            break;
+        case DCV_ACT_RELU:
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[v] = z[v] > 0.f ? z[v] : 0.f;
+            break;
+        default:
+#pragma unroll
+            for (int v = 0; v < 4; ++v) h[v] = act_fwd(act, z[v]);
+            break;
+    }
+    return h;
+}
+__device__ __forceinline__ sv4f snet_actgrad4(int act, sv4f h) {
+    sv4f g;
+    switch (act) {
+        case DCV_ACT_NONE: g = sv4f{1.f, 1.f, 1.f, 1.f}; break;
+        case DCV_ACT_LEAKY_RELU:
+#pragma unroll
+            for (int v = 0; v < 4; ++v) g[v] = h[v] > 0.f ? 1.f : 0.01f;
+            break;
+        case DCV_ACT_RELU:
+#pragma unroll
+            for (int v = 0; v < 4; ++v) g[v] = h[v] > 0.f ? 1.f : 0.f;
+            break;
+        default:
+#pragma unroll
+            for (int v = 0; v < 4; ++v) g[v] = act_grad_from_out(act, h[v]);
+            break;
+    }
+    return g;
+}
+
+constexpr int kSnetMaxTiles = 8;   // column tiles of a layer per wave (input gradients are held in registers across a barrier)
+
+#define SNET_NK_SWITCH(nk, CALL)          \
+    switch (nk) {                         \
+        case 1: { CALL(1) } break;        \
+        case 2: { CALL(2) } break;        \
+        case 4: { CALL(4) } break;        \
+        case 8: { CALL(8) } break;        \
+        default: { CALL(16) } break;      \
+    }
 
 template <int TR>
-__global__ __launch_bounds__(256) void snet_ae_kernel(SnetArgs a) {
-    constexpr int RG = TR / 16, CG = 4 / RG;
+__global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
+    constexpr int NT = kSnetThreads;
+    constexpr int RG = TR / 16, CG = kSnetWaves / RG;
     extern __shared__ __attribute__((aligned(16))) float sl[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rg = wave / CG, cg = wave % CG;
     const int q = lane >> 4, n = lane & 15;
     const int L = a.L;
-    // ---- stage every weight and bias (zero-padded to 16 x 16 tiles, row stride pin + 4)
-    for (int l = 0; l < L; ++l) {
-        const SnetLayer& y = a.l[l];
-        const float* W = a.params + y.w_off;
-        float* dst = sl + y.lw;
-        if ((y.in & 3) == 0) {
-            const int c4 = y.pin >> 2, in4 = y.in >> 2;
-            for (int i = t; i < y.pout * c4; i += 256) {
-                const int o = i / c4, c = i - o * c4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (o < y.out && c < in4) v = *reinterpret_cast<const float4*>(W + (int64_t)o * y.in + 4 * c);
-                *reinterpret_cast<float4*>(dst + o * y.pws + 4 * c) = v;
-            }
-        } else {
-            for (int i = t; i < y.pout * y.pin; i += 256) {
-                const int o = i / y.pin, c = i - o * y.pin;
-                dst[o * y.pws + c] = (o < y.out && c < y.in) ? W[(int64_t)o * y.in + c] : 0.f;
+    SNET_STAMP(0);
+    // ---- stage every weight image and bias (zero-padded, row stride pin + 4) through the plan's staging table: one flat
+    //      space of 16-byte units over all layers, twelve independent loads in flight per thread and pass -- two dependent
+    //      round trips in all (table entry, then data).  Per-layer loops cost one L2 round trip per pass (8-11 us).
+    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
+        int2 e[12];
+        float4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = i0 + NT * u;
+            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e[u].x >= 0) {
+                const float* src = a.params + e[u].x;
+                const int nv = (e[u].y >> 20) & 7;
+                if ((e[u].y >> 24) & 1) {
+                    v[u] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v[u].x = src[0];
+                    if (nv > 1) v[u].y = src[1];
+                    if (nv > 2) v[u].z = src[2];
+                    if (nv > 3) v[u].w = src[3];
+                }
             }
         }
-        for (int i = t; i < y.pout; i += 256) sl[y.lb + i] = i < y.out ? a.params[y.b_off + i] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
     }
-    // ---- input tile H_0 (rows past the batch: zeros)
+    SNET_STAMP(1);
+    // ---- input tile H_0 (rows past the batch: zeros), 16-byte loads where the matrix allows
     const int64_t r0 = (int64_t)blockIdx.x * TR;
     {
         const int F = a.l[0].in, p0 = a.l[0].pin, ps0 = a.ps[0];
         float* H0 = sl + a.lh[0];
-        for (int i = t; i < TR * p0; i += 256) {
-            const int r = i / p0, c = i - r * p0;
-            float v = 0.f;
-            if (r0 + r < a.R && c < F) v = a.Xn[a.rows.template get<true>(r0 + r) * a.ld + c];
-            H0[r * ps0 + c] = v;
+        if ((F & 3) == 0 && (a.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Xn) & 15) == 0) {
+            const int sh = a.l[0].c4_shift, f4 = F >> 2, tot = TR << sh;
+            for (int i0 = t; i0 < tot; i0 += 4 * NT) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + NT * u, r = i >> sh, c = i - (r << sh);
+                    v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < tot && r0 + r < a.R && c < f4) v[u] = *reinterpret_cast<const float4*>(a.Xn + a.rows.template get<true>(r0 + r) * a.ld + 4 * c);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + NT * u, r = i >> sh, c = i - (r << sh);
+                    if (i < tot) *reinterpret_cast<float4*>(H0 + r * ps0 + 4 * c) = v[u];
+                }
+            }
+        } else {
+            for (int i = t; i < TR * p0; i += NT) {
+                const int r = i / p0, c = i - r * p0;
+                float v = 0.f;
+                if (r0 + r < a.R && c < F) v = a.Xn[a.rows.template get<true>(r0 + r) * a.ld + c];
+                H0[r * ps0 + c] = v;
+            }
         }
     }
     __syncthreads();
+    SNET_STAMP(2);
     // ---- forward chain
     double sse = 0.0;
     for (int l = 0; l < L; ++l) {
@@ -151,42 +273,51 @@ __global__ __launch_bounds__(256) void snet_ae_kernel(SnetArgs a) {
         float* Hout = sl + a.lh[l + 1];
         const int psin = a.ps[l], pso = a.ps[l + 1];
         const bool last = l == L - 1;
-        for (int ct = cg; ct < y.pout / 16; ct += CG) {
-            const sv4f acc = snet_fwd_tile(Hin, psin, sl + y.lw, y.pws, rg, ct, y.pin, lane);
-            const int col = ct * 16 + n;
-            const float bias = sl[y.lb + col];
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const int row = rg * 16 + 4 * q + v;
-                float h = col < y.out ? act_fwd(y.act, acc[v] + bias) : 0.f;
-                if (last) {
-                    // autoencoder loss on the spot: e = (y - xn) * range ; dY = scale * (y - xn) * range^2 * act'(y)
-                    float g = 0.f;
-                    if (col < y.out && r0 + row < a.R) {
-                        const float x = sl[a.lh[0] + row * a.ps[0] + col];
-                        const float rgv = a.range[col];
-                        const float ev = (h - x) * rgv;
-                        sse += (double)ev * (double)ev;
-                        g = a.scale * (h - x) * rgv * rgv * act_grad_from_out(y.act, h);
-                    }
-                    h = g;   // H_L now holds dZ_L
-                }
-                Hout[row * pso + col] = h;
-            }
+        const float* ap = Hin + (rg * 16 + n) * psin + 4 * q;
+        const float* W = sl + y.lw + n * y.pws + 4 * q;
+        const float* H0row = sl + a.lh[0] + (rg * 16 + 4 * q) * a.ps[0];
+#define SNET_FWD(NK)                                                                                                        \
+        SnetFrags<NK> A;                                                                                                     \
+        A.load(ap);                                                                                                          \
+        for (int ct = cg; ct < y.nk_out; ct += CG) {                                                                         \
+            const sv4f acc = snet_fwd_tile<NK>(A, W + ct * 16 * y.pws);                                                      \
+            const int col = ct * 16 + n;                                                                                     \
+            const float bias = sl[y.lb + col];                                                                               \
+            sv4f h = snet_act4(y.act, acc + bias);                                                                           \
+            if (col >= y.out) h = sv4f{0.f, 0.f, 0.f, 0.f};                                                                  \
+            if (last) {   /* autoencoder loss on the spot: e = (y - xn) * range ; dY = scale * (y - xn) * range^2 * act'(y) */ \
+                const float rgv = col < y.out ? a.range[col] : 0.f;                                                          \
+                const sv4f dh = snet_actgrad4(y.act, h);                                                                     \
+                _Pragma("unroll") for (int v = 0; v < 4; ++v) {                                                              \
+                    float g = 0.f;                                                                                           \
+                    if (col < y.out && r0 + rg * 16 + 4 * q + v < a.R) {                                                     \
+                        const float x = H0row[v * a.ps[0] + col];                                                            \
+                        const float ev = (h[v] - x) * rgv;                                                                   \
+                        sse += (double)ev * (double)ev;                                                                      \
+                        g = a.scale * (h[v] - x) * rgv * rgv * dh[v];                                                        \
+                    }                                                                                                        \
+                    h[v] = g;   /* H_L now holds dZ_L */                                                                     \
+                }                                                                                                            \
+            }                                                                                                                \
+            _Pragma("unroll") for (int v = 0; v < 4; ++v) Hout[(rg * 16 + 4 * q + v) * pso + col] = h[v];                    \
         }
+        SNET_NK_SWITCH(y.nk_in, SNET_FWD)
+#undef SNET_FWD
         __syncthreads();
+        SNET_STAMP(3 + l);
     }
     // ---- squared error of the tile -> partial -> (ticket) the step's loss record
     {
         double* red = reinterpret_cast<double*>(sl + a.lred);
         red[t] = sse;
         __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
+        for (int off = NT / 2; off > 0; off >>= 1) {
             if (t < off) red[t] += red[t + off];
             __syncthreads();
         }
         if (t == 0) handoff_store(a.sse_part + blockIdx.x, red[0]);
     }
+    SNET_STAMP(20);
     // ---- backward chain: dZ_l lives in the buffer of H_{l+1}; dZ_{l-1} is written over H_l once the weight gradient
     //      of layer l (which reads H_l) has been formed by every wave
     if (a.train) {
@@ -198,57 +329,77 @@ __global__ __launch_bounds__(256) void snet_ae_kernel(SnetArgs a) {
             // input gradient first, kept in registers
             sv4f dg[kSnetMaxTiles];
             if (l > 0) {
-#pragma unroll
-                for (int j = 0; j < kSnetMaxTiles; ++j) {
-                    const int it = cg + j * CG;
-                    if (it < y.pin / 16) dg[j] = snet_dgrad_tile(dZ, psz, sl + y.lw, y.pws, rg, it, y.pout, lane);
+                const float* ap = dZ + (rg * 16 + n) * psz + 4 * q;
+                const float* W = sl + y.lw + (4 * q) * y.pws + n;
+#define SNET_DGRAD(NK)                                                                                   \
+                SnetFrags<NK> A;                                                                         \
+                A.load(ap);                                                                              \
+                _Pragma("unroll") for (int j = 0; j < kSnetMaxTiles; ++j) {                              \
+                    const int it = cg + j * CG;                                                          \
+                    if (it < y.nk_in) dg[j] = snet_dgrad_tile<NK>(A, W + it * 16, y.pws);                \
                 }
+                SNET_NK_SWITCH(y.nk_out, SNET_DGRAD)
+#undef SNET_DGRAD
             }
-            // weight gradient of the tile: the (pout / 16) x (pin / 16) tiles round-robin over the four waves
+            SNET_STAMP(40 + l);
+            // weight gradient of the tile: the nk_out x nk_in tiles round-robin over the waves
             {
-                const int nto = y.pout / 16, nti = y.pin / 16;
+                const int nti = y.nk_in, ntot = y.nk_out * nti;
                 float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.out * y.in;
-                for (int tile = wave; tile < nto * nti; tile += 4) {
-                    const int ot = tile / nti, it = tile - ot * nti;
-                    const sv4f acc = snet_wgrad_tile<TR>(dZ, psz, Hin, psh, ot, it, lane);
+                int ot = 0, it = wave;
+                while (it >= nti) { it -= nti; ++ot; }
+#pragma unroll 2
+                for (int tile = wave; tile < ntot; tile += kSnetWaves) {
+                    const sv4f acc = snet_wgrad_tile<TR>(dZ + q * psz + ot * 16 + n, psz, Hin + q * psh + it * 16 + n, psh);
                     const int i = it * 16 + n;
 #pragma unroll
                     for (int v = 0; v < 4; ++v) {
                         const int o = ot * 16 + 4 * q + v;
                         if (o < y.out && i < y.in) pw[(int64_t)o * y.in + i] = acc[v];
                     }
+                    it += kSnetWaves;
+                    while (it >= nti) { it -= nti; ++ot; }
                 }
+                SNET_STAMP(48 + l);
                 // bias gradient: column sums of dZ_l over the tile's rows, rows in index order
-                for (int o = t; o < y.out; o += 256) {
+                // (four threads per column, a quarter of the rows each, combined by two shuffles: a fixed order)
+                for (int o4 = t; o4 < 4 * y.pout; o4 += NT) {
+                    const int o = o4 >> 2, part = o4 & 3;
                     float s = 0.f;
-#pragma unroll 8
-                    for (int r = 0; r < TR; ++r) s += dZ[r * psz + o];
-                    a.part[y.pb_off + (int64_t)blockIdx.x * y.out + o] = s;
+#pragma unroll
+                    for (int r = 0; r < TR / 4; ++r) s += dZ[(part * (TR / 4) + r) * psz + o];
+                    s += __shfl_xor(s, 1, 64);
+                    s += __shfl_xor(s, 2, 64);
+                    if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.out + o] = s;
                 }
             }
+            SNET_STAMP(21 + 2 * l);
             if (l == 0) break;
             __syncthreads();   // every wave is done reading H_l
             const int act_prev = a.l[l - 1].act, out_prev = a.l[l - 1].out;
 #pragma unroll
             for (int j = 0; j < kSnetMaxTiles; ++j) {
                 const int it = cg + j * CG;
-                if (it < y.pin / 16) {
+                if (it < y.nk_in) {
                     const int col = it * 16 + n;
+                    float* p = Hin + (rg * 16 + 4 * q) * psh + col;
+                    sv4f h;
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int row = rg * 16 + 4 * q + v;
-                        float* p = Hin + row * psh + col;
-                        *p = col < out_prev ? dg[j][v] * act_grad_from_out(act_prev, *p) : 0.f;
-                    }
+                    for (int v = 0; v < 4; ++v) h[v] = p[v * psh];
+                    const sv4f dh = snet_actgrad4(act_prev, h);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) p[v * psh] = col < out_prev ? dg[j][v] * dh[v] : 0.f;
                 }
             }
             __syncthreads();
         }
     }
+    SNET_STAMP(60);
     // ---- last workgroup: total squared error in block order, loss record
     unsigned* flag = reinterpret_cast<unsigned*>(sl + a.lred);
     __syncthreads();
     if (!handoff_arrive_last(a.ticket, gridDim.x, flag)) return;
+    SNET_STAMP(61);
     if (t < 64) {
         double tot = 0.0;
         for (int b0 = t; b0 < (int)gridDim.x; b0 += 64) tot += handoff_load(a.sse_part + b0);
@@ -272,6 +423,8 @@ struct SnetPlan {
     float* part;         // gradient partials
     int64_t part_floats; // capacity
     int64_t per_wg;      // floats of one workgroup's partials over all layers (dense: sum out * in + out)
+    unsigned long long* stamps;   // 64 words, or null (DCV_SNET_STAMPS=1)
+    int2* stage_tab;     // device copy of the staging table
 };
 
 static bool snet_disabled() {
@@ -287,43 +440,84 @@ static bool snet_build(dcv_mlp* m) {
     if (!pl) return false;
     SnetArgs& a = pl->base;
     a.L = m->L;
-    int fl = 0;
+    int fl = 0, u4 = 0;
     int64_t per_wg = 0;
+    std::vector<int2> tab;
     for (int l = 0; l < m->L; ++l) {
         const LayerPlan& p = m->layers[l];
         SnetLayer& y = a.l[l];
         y.in = p.in; y.out = p.out; y.act = p.act;
-        y.pin = (p.in + 15) / 16 * 16;
-        y.pout = (p.out + 15) / 16 * 16;
-        if (y.pin > 16 * 2 * kSnetMaxTiles || y.pout > 16 * 2 * kSnetMaxTiles) { delete pl; return false; }
+        auto pad = [](int w) { int k = 1; while (16 * k < w) k *= 2; return 16 * k; };   // 16 * 2^j: compile-time contraction lengths
+        y.pin = pad(p.in);
+        y.pout = pad(p.out);
+        if (y.pin > 256 || y.pout > 256) { delete pl; return false; }
+        y.nk_in = y.pin / 16;
+        y.nk_out = y.pout / 16;
+        y.u4_begin = u4;
+        u4 += y.pout * (y.pin / 4);
+        y.c4_shift = 0;
+        while ((1 << y.c4_shift) < y.pin / 4) ++y.c4_shift;
         y.w_off = p.w_off; y.b_off = p.b_off;
         y.pws = y.pin + 4;
         y.lw = fl; fl += y.pout * y.pws;
         y.lb = fl; fl += y.pout;
         per_wg += (int64_t)p.out * p.in + p.out;
+        const bool vec = (p.in % 4 == 0) && (p.w_off % 4 == 0);
+        for (int o = 0; o < y.pout; ++o)
+            for (int c = 0; c < y.pin / 4; ++c) {
+                const int nv = o < p.out ? (p.in - 4 * c >= 4 ? 4 : (p.in - 4 * c > 0 ? p.in - 4 * c : 0)) : 0;
+                tab.push_back(make_int2(nv > 0 ? (int)(p.w_off + (int64_t)o * p.in + 4 * c) : -1,
+                                        (y.lw + o * y.pws + 4 * c) | (nv << 20) | ((vec && nv == 4 ? 1 : 0) << 24)));
+            }
+        for (int c = 0; c < y.pout / 4; ++c) {
+            const int nv = p.out - 4 * c >= 4 ? 4 : (p.out - 4 * c > 0 ? p.out - 4 * c : 0);
+            tab.push_back(make_int2(nv > 0 ? (int)(p.b_off + 4 * c) : -1, (y.lb + 4 * c) | (nv << 20) | ((nv == 4 && p.b_off % 4 == 0 ? 1 : 0) << 24)));
+        }
     }
     pl->per_wg = per_wg;
+    (void)u4;
+    if (fl >= (1 << 20) || m->n_params >= (1ll << 31)) { delete pl; return false; }
+    pl->stage_tab = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&pl->stage_tab), tab.size() * sizeof(int2)) != hipSuccess ||
+        hipMemcpy(pl->stage_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (pl->stage_tab) (void)hipFree(pl->stage_tab);
+        delete pl;
+        return false;
+    }
+    a.stage_tab = pl->stage_tab;
+    a.stage_n = (int)tab.size();
     const size_t lds_max = 160 * 1024;
+    static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();   // 16 | 32: force the rows per workgroup
     for (int TR : {32, 16}) {
+        if (tr_env != 0 && tr_env != TR) continue;
         int f = fl;
         for (int l = 0; l <= m->L; ++l) {
-            const int P = ((l == 0 ? m->layers[0].in : m->layers[l - 1].out) + 15) / 16 * 16;
+            const int P = l == 0 ? a.l[0].pin : a.l[l - 1].pout;
+            if (l > 0 && l < m->L && a.l[l].pin != P) { f = 1 << 30; break; }   // (always equal: both pad the same width)
             a.ps[l] = P + 4;
             a.lh[l] = f;
             f += TR * (P + 4);
         }
         f = (f + 3) / 4 * 4;
         a.lred = f;
-        f += 512;   // 256 doubles
+        f += 2 * kSnetThreads;   // kSnetThreads doubles
         if ((size_t)f * sizeof(float) <= lds_max) {
             pl->TR = TR;
             pl->lds_bytes = (size_t)f * sizeof(float);
             pl->part = nullptr;
             pl->part_floats = 0;
+            pl->stamps = nullptr;
+            {
+                const char* e = getenv("DCV_SNET_STAMPS");
+                if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void**>(&pl->stamps), 64 * sizeof(unsigned long long)) == hipSuccess)
+                    (void)hipMemset(pl->stamps, 0, 64 * sizeof(unsigned long long));
+            }
             m->snet = pl;
             return true;
         }
     }
+    (void)hipFree(pl->stage_tab);
     delete pl;
     return false;
 }
@@ -332,6 +526,8 @@ void snet_free(dcv_mlp* m) {
     SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
     if (!pl) return;
     if (pl->part) (void)hipFree(pl->part);
+    if (pl->stamps) (void)hipFree(pl->stamps);
+    if (pl->stage_tab) (void)hipFree(pl->stage_tab);
     delete pl;
     m->snet = nullptr;
 }
@@ -392,6 +588,7 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     a.log_count = m->log_count;
     a.log_cap = m->log_cap;
     a.log_width = m->log_width;
+    a.stamps = pl->stamps;
     auto launch = [&](auto kern) -> int {
         static int attr_state[2] = {0, 0};   // 0 unknown, 1 set, -1 refused by the runtime (the fused form is then off)
         const int slot = pl->TR == 32 ? 0 : 1;
@@ -401,7 +598,7 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
             attr_state[slot] = e == hipSuccess ? 1 : -1;
         }
         if (attr_state[slot] < 0) return 1;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), pl->lds_bytes, s, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), pl->lds_bytes, s, a);
         DCV_CHECK_LAUNCH();
         return DCV_OK;
     };
@@ -409,3 +606,15 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
 }
 
 }  // namespace dcv
+
+// diagnostic (tools/dbg/snet_probe.py; not part of include/dcv.h): the 64 phase stamps of the last fused launch
+// (s_memrealtime ticks of 10 ns), 0 where not taken; needs DCV_SNET_STAMPS=1 at engine creation
+extern "C" int dcv_debug_snet_stamps(dcv_mlp* m, unsigned long long* out_h) {
+    using namespace dcv;
+    if (!m || !out_h) return DCV_EINVAL;
+    SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
+    if (!pl || !pl->stamps) return 1;
+    DCV_CHECK_HIP(hipDeviceSynchronize());
+    DCV_CHECK_HIP(hipMemcpy(out_h, pl->stamps, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return DCV_OK;
+}

@@ -78,6 +78,71 @@ def test_c3_lagged_covariance_properties():
     torch.cuda.empty_cache()
 
 
+def test_c3_tica_htica_calculators_fullsize(tmp_path):
+    """The tica / htica CALCULATORS (cv_calculator.py:2249-2267, :2311-2384) at BASELINE C3's size, 5M x 256, lag 10 -- not only
+    the covariance kernel under them.  Size-independent checks: the TICA weights solve the generalised eigenproblem of
+    the covariances the kernel-level path gives for the same matrix (residual, C0-orthonormality, eigenvalues in
+    descending order inside (0, 1)); they agree with the host solve of those kernel-level covariances; the
+    projections are min-max normalised to [-1, 1]; hTICA (10 subspaces of 5 features) obeys the same equations inside the
+    span it works in and its leading eigenvalue cannot exceed TICA's (a Rayleigh quotient over a subspace)."""
+    from deep_cartograph_amd import hip, linalg
+    from deep_cartograph_amd.cv_calculator import cv_calculators_map
+    from deep_cartograph_amd.synth import synth_features
+
+    n, F, lag, d = 5_000_000, 256, 10, 3
+    X = synth_features(n, F, k_slow=4, device="cuda")
+    cfg = {"dimension": d, "lag_time": lag, "features_normalization": "mean_std", "num_subspaces": 10, "subspaces_dimension": 5,
+           "tica_regularization": 1e-6}
+    out = {}
+    for cv in ("tica", "htica"):
+        calc = cv_calculators_map[cv](json_copy(cfg), str(tmp_path / cv))
+        calc.set_training_matrix(X.clone())
+        calc.create_output_folders()
+        calc.compute_cv()
+        calc.set_labels()
+        calc.normalize_cv()
+        proj = calc.project_data(calc.training_data, normalize_data=False)
+        pr = proj.numpy() if not proj.is_cuda else proj.cpu().numpy()
+        assert pr.shape == (n, d)
+        np.testing.assert_allclose(pr.min(0), -1.0, atol=2e-5)
+        np.testing.assert_allclose(pr.max(0), 1.0, atol=2e-5)
+        out[cv] = (np.asarray(calc.cv, dtype=np.float64), calc)
+    # the covariance-level path on the same standardised matrix
+    calc = out["tica"][1]
+    Xn = calc.training_data          # standardised in place by the linear calculators
+    P = n - lag
+    shift = torch.zeros(F, dtype=torch.float32, device="cuda")
+    raw = hip.lagged_cov_raw(Xn, P, lag, shift).cpu().numpy()
+    _, C0, Ct = hip.covariances_from_raw(raw, P, F)
+    W = out["tica"][0]
+    C0r = C0 + 1e-6 * np.eye(F)
+    lam = np.diag(W.T @ Ct @ W) / np.diag(W.T @ C0r @ W)
+    assert np.all(np.diff(lam) <= 1e-9) and np.all(lam > 0) and np.all(lam < 1)
+    G = W.T @ C0 @ W
+    np.testing.assert_allclose(G / np.sqrt(np.outer(np.diag(G), np.diag(G))), np.eye(d), atol=1e-5)   # C0-orthogonal directions
+    resid = Ct @ W - C0r @ W * lam
+    assert np.max(np.abs(resid)) < 2e-5 * np.max(np.abs(Ct @ W))
+    ev, evec = linalg.tica_eigh(C0, Ct, 1e-6, d)
+    np.testing.assert_allclose(lam, ev, rtol=1e-6)
+    Wh = np.asarray(evec, dtype=np.float64)
+    for k in range(d):   # same directions up to sign and scale as the host solve of the kernel-level covariances
+        c = abs(W[:, k] @ C0 @ Wh[:, k]) / np.sqrt((W[:, k] @ C0 @ W[:, k]) * (Wh[:, k] @ C0 @ Wh[:, k]))
+        assert abs(c - 1.0) < 1e-6, (k, c)
+    Wt = out["htica"][0]
+    lam_h = np.diag(Wt.T @ Ct @ Wt) / np.diag(Wt.T @ C0 @ Wt)
+    assert np.all(lam_h > 0) and lam_h[0] <= lam[0] + 1e-6
+    Gh = Wt.T @ C0 @ Wt
+    np.testing.assert_allclose(Gh / np.sqrt(np.outer(np.diag(Gh), np.diag(Gh))), np.eye(d), atol=1e-4)
+    del X
+    torch.cuda.empty_cache()
+
+
+def json_copy(x):
+    import json
+
+    return json.loads(json.dumps(x))
+
+
 def test_c4_step_decomposes_over_two_shards(c4_matrix):
     """The bench's Deep-TICA step (524 208 pairs of the 10M x 512 matrix, MLP 512-256-128-4) decomposes the way the
     data-parallel run computes it: statistics of two half batches add up to the whole batch's, and with the summed

@@ -269,7 +269,9 @@ def test_deeptica_row_sharing_equivalence():
     eng.close()
 
 
-DT_TRAIN_TOL = {"loss": 2e-3, "w": 3e-4, "b": 3e-4}   # provisional: 3 x the measured deviations
+# measured after 30 Adam steps: loss 4.6e-6 (relative), weights 1.3e-7, hidden biases 7.6e-8.  The other side is the FLOAT32 oracle,
+# whose own rounding depends on the host BLAS of the box it runs on: ~7 x the measured deviations rather than 3 x
+DT_TRAIN_TOL = {"loss": 3e-5, "w": 1e-6, "b": 6e-7}
 
 
 def test_deeptica_training_matches_oracle():

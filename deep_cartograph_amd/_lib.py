@@ -9,7 +9,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libdcv.so")
 
 DCV_MAX_LAYERS = 16
 ACT = {None: 0, "linear": 0, "leaky_relu": 1, "relu": 2, "tanh": 3, "elu": 4, "softplus": 5, "shifted_softplus": 6, "custom_sigmoid": 7}
-OPTIMIZER = {"Adam": 0, "AdamW": 1, "SGD": 2, "RMSprop": 3, "Adagrad": 4}
+OPTIMIZER = {"Adam": 0, "AdamW": 1, "SGD": 2, "RMSprop": 3, "Adagrad": 4, "Adamax": 5, "NAdam": 6, "RAdam": 7, "Adadelta": 8, "ASGD": 9, "Rprop": 10}
 MODEL_DEEPTICA = 1
 MODEL_AE = 2
 
@@ -38,8 +38,12 @@ class MlpDesc(C.Structure):
         ("alpha", C.c_double),
         ("lr_decay", C.c_double),
         ("initial_accumulator_value", C.c_double),
+        ("opt_p", C.c_double * 4),
         ("dropout", C.c_float * DCV_MAX_LAYERS),
         ("seed", C.c_uint64),
+        ("batchnorm", C.c_int32 * DCV_MAX_LAYERS),
+        ("bn_eps", C.c_double),
+        ("bn_momentum", C.c_double),
     ]
 
 
@@ -87,6 +91,7 @@ SIGNATURES = {
     "dcv_mlp_set_upper_grads_callback": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_dp_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _P, _P]),
     "dcv_mlp_set_rank": (C.c_int, [_P, _I32]),
+    "dcv_mlp_bn_state": (C.c_int, [_P, _I32, _P, _P, C.POINTER(_I64), _I32, _P]),
     "dcv_mlp_layer_output": (C.c_int, [_P, _I32, _I64, _P, _P]),
     "dcv_mlp_train_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_eval_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
@@ -139,8 +144,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.dcv_abi_version()
-    if ver != 2:
-        raise DcvError(f"libdcv.so ABI version {ver}, expected 2 (rebuild: make -C deep_cartograph_amd/csrc)")
+    if ver != 3:
+        raise DcvError(f"libdcv.so ABI version {ver}, expected 3 (rebuild: make -C deep_cartograph_amd/csrc)")
     _lib = lib
     return lib
 

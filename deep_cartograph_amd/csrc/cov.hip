@@ -5,6 +5,7 @@
 // same matrix `lag` rows further down -- pairing costs no bytes (the reference materialises two
 // copies, cv_calculator.py:2247).
 #include "gemm_kernels.h"
+#include <stdlib.h>
 
 namespace dcv {
 
@@ -24,7 +25,8 @@ struct CovPlan {
 static CovPlan cov_plan(int64_t n_pairs, int F, int lag) {
     CovPlan p;
     p.nb = lag > 0 ? 2 : 1;
-    p.k_chunk = kCovChunkRows;
+    static const int64_t chunk_env = [] { const char* e = getenv("DCV_COV_CHUNK"); return e ? (int64_t)atoll(e) : (int64_t)0; }();   // diagnostic override
+    p.k_chunk = chunk_env >= 64 ? chunk_env / 32 * 32 : kCovChunkRows;
     const size_t per_split = (size_t)p.nb * F * F * sizeof(float);
     while (cdiv(n_pairs, p.k_chunk) * per_split > kCovMaxSlabBytes) p.k_chunk *= 2;
     // A split count that is a multiple of 8 lets the kernel's XCD-aware map put the output tiles of one chunk on one XCD,
@@ -36,6 +38,9 @@ static CovPlan cov_plan(int64_t n_pairs, int F, int lag) {
             p.k_chunk = kc;
             break;
         }
+    // the shortened chunk may push the slabs past the cap again: lengthen in whole stages until they fit (the XCD-aware map
+    // then falls back to the plain one when the count is no multiple of 8 -- slower, never wrong)
+    while (cdiv(n_pairs, p.k_chunk) * per_split > kCovMaxSlabBytes) p.k_chunk += 32;
     p.splits = cdiv(n_pairs, p.k_chunk);
     p.stats_ws = align_up(dcv_col_stats_workspace(n_pairs, F), 256);
     p.sums = align_up((size_t)3 * 4 * F * sizeof(double), 256);

@@ -71,7 +71,7 @@ struct ReduceDesc {
     int splits, bblocks;
 };
 struct ReduceArgs {
-    ReduceDesc l[DCV_MAX_LAYERS];
+    ReduceDesc l[2 * DCV_MAX_LAYERS];   // [0, L): the Linear layers; [L, 2 L): weight / bias of the batch normalisation behind layer l - L (empty without one)
     int L;
 };
 
@@ -86,6 +86,7 @@ struct OptArgs {
     // rounded once, exactly as there ((float)(1 - 0.999) is not 1.f - 0.999f)
     float w1, w2;     // 1 - beta1 (Adam) / 1 - dampening (SGD) ; 1 - beta2 (Adam) / 1 - alpha (RMSprop)
     float decay;      // AdamW: 1 - lr * weight_decay
+    float p0, p1, p2, p3;   // further per-step scalars of Adamax / NAdam / RAdam / Adadelta / ASGD / Rprop (next_opt_args)
 };
 __device__ __forceinline__ void opt_update(int64_t i, float gi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
                                            float* __restrict__ s3, const OptArgs& a) {
@@ -139,6 +140,73 @@ __device__ __forceinline__ void opt_update(int64_t i, float gi, float* __restric
             } else {
                 p[i] = pi - a.lr * (gi / avg);
             }
+            break;
+        }
+        case DCV_OPT_ADAMAX: {   // _single_tensor_adamax: s1 = exp_avg, s2 = exp_inf
+            if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+            float mi = s1[i];
+            mi = mi + (gi - mi) * a.w1;                                           // exp_avg.lerp_(grad, 1 - beta1)
+            const float ui = fmaxf(s2[i] * a.b2, fabsf(gi) + a.eps);              // maximum(exp_inf * beta2, |grad| + eps)
+            s1[i] = mi;
+            s2[i] = ui;
+            p[i] = pi - a.c1 * (mi / ui);                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
+            break;
+        }
+        case DCV_OPT_NADAM: {    // _single_tensor_nadam: p0 = -lr (1 - mu) / (1 - mu_product), p1 = -lr mu_next / (1 - mu_product_next), c2 = 1 - beta2^t
+            if (a.wd != 0.f) {
+                if (a.flag) pi = pi * a.decay;                                     // decoupled: param.mul_(1 - lr * weight_decay)
+                else gi = fmaf(a.wd, pi, gi);
+            }
+            float mi = s1[i], vi = s2[i];
+            mi = mi + (gi - mi) * a.w1;
+            vi = vi * a.b2 + a.w2 * gi * gi;
+            const float denom = sqrtf(vi / a.c2) + a.eps;                          // exp_avg_sq.div(bias_correction2).sqrt().add(eps)
+            s1[i] = mi;
+            s2[i] = vi;
+            pi = pi + a.p0 * (gi / denom);
+            p[i] = pi + a.p1 * (mi / denom);
+            break;
+        }
+        case DCV_OPT_RADAM: {    // _single_tensor_radam: c1 = 1 - beta1^t, c2 = sqrt(1 - beta2^t), p0 = rect (0: rho_t <= 5)
+            if (a.wd != 0.f) {
+                if (a.flag) pi = pi * a.decay;
+                else gi = fmaf(a.wd, pi, gi);
+            }
+            float mi = s1[i], vi = s2[i];
+            mi = mi + (gi - mi) * a.w1;
+            vi = vi * a.b2 + a.w2 * gi * gi;
+            s1[i] = mi;
+            s2[i] = vi;
+            const float mhat = mi / a.c1;
+            if (a.p0 > 0.f) p[i] = pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0;
+            else p[i] = pi - mhat * a.lr;
+            break;
+        }
+        case DCV_OPT_ADADELTA: { // _single_tensor_adadelta: s1 = square_avg, s2 = acc_delta, b2 = rho, w2 = 1 - rho
+            if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+            const float sq = s1[i] * a.b2 + a.w2 * gi * gi;
+            const float acc = s2[i];
+            const float delta = sqrtf(acc + a.eps) / sqrtf(sq + a.eps) * gi;
+            s1[i] = sq;
+            s2[i] = acc * a.b2 + a.w2 * delta * delta;
+            p[i] = pi - a.lr * delta;
+            break;
+        }
+        case DCV_OPT_ASGD: {     // _single_tensor_asgd: p0 = 1 - lambd * eta, p1 = eta (the averaged copy ax is not kept)
+            if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
+            pi = pi * a.p0;
+            p[i] = pi - a.p1 * gi;
+            break;
+        }
+        case DCV_OPT_RPROP: {    // _single_tensor_rprop: s1 = prev, s2 = step_size; p0 / p1 = eta minus / plus, p2 / p3 = step bounds
+            const float sg = gi * s1[i];
+            const float f = sg > 0.f ? a.p1 : (sg < 0.f ? a.p0 : 1.f);
+            const float st = fminf(fmaxf(s2[i] * f, a.p2), a.p3);
+            s2[i] = st;
+            if (sg < 0.f) gi = 0.f;
+            const float sgn = gi > 0.f ? 1.f : (gi < 0.f ? -1.f : 0.f);
+            p[i] = pi - sgn * st;
+            s1[i] = gi;
             break;
         }
         default: {   // DCV_OPT_ADAGRAD
@@ -1066,7 +1134,7 @@ static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStre
 // (Not with dropout in a training step: the reference evaluates x_t and x_lag in two forward calls with independent masks.)
 static bool shared_rows(const dcv_mlp* m, const int64_t* idx, int batch) {
     return m->desc.model == DCV_MODEL_DEEPTICA && idx == nullptr && m->desc.lag >= 1 && m->desc.lag <= batch && !m->no_row_sharing &&
-           !(m->fwd_train && m->any_drop);
+           !(m->fwd_train && (m->any_drop || m->any_bn));   // separate forward calls: independent dropout masks, separate batch statistics
 }
 // dropout behind Linear `layer` in the current step (off in evaluation mode)
 static DropCfg drop_cfg(const dcv_mlp* m, int layer) {
@@ -1119,7 +1187,7 @@ static size_t head_lds_bytes(int D, int K) {
 }
 static bool head_fusable(const dcv_mlp* m) {
     static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
-    if (off || m->L < 2) return false;
+    if (off || m->L < 2 || m->any_bn) return false;
     if (m->desc.dropout[m->L - 1] > 0.f) return false;   // dropout on the network output: general kernels
     const LayerPlan& p = m->layers[m->L - 1];
     const LayerPlan& q = m->layers[m->L - 2];
@@ -1146,7 +1214,7 @@ static void mlp_free(dcv_mlp* m) {
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->opt_aux); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
-    for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); }
+    for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); f(l.Y); f(l.rm); f(l.rv); f(l.bn_stat); f(l.bn_part); f(l.bn_gpart); f(l.bn_bpart); }
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     f(m->tail.ws); f(m->tail.cnt);
     for (int i = 0; i < 4; ++i) if (m->gexec[i]) (void)hipGraphExecDestroy(m->gexec[i]);
@@ -1166,6 +1234,7 @@ static int dmalloc(T** p, size_t count) {
 
 }  // namespace dcv
 
+static int reset_bn_state(dcv_mlp* m, hipStream_t s);
 // optimiser state as a freshly constructed torch optimiser holds it
 static int reset_opt_state(dcv_mlp* m, hipStream_t s) {
     const size_t bytes = m->n_params * sizeof(float);
@@ -1176,6 +1245,12 @@ static int reset_opt_state(dcv_mlp* m, hipStream_t s) {
         hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, m->adam_v, m->n_params, (float)m->desc.initial_accumulator_value);
         DCV_CHECK_LAUNCH();
     }
+    if (m->desc.optimizer == DCV_OPT_RPROP) {   // step_size starts at lr
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, m->adam_v, m->n_params, (float)m->desc.lr);
+        DCV_CHECK_LAUNCH();
+    }
+    m->nadam_mu_product = 1.0;
+    m->asgd_eta = (double)(float)m->desc.lr;
     m->adam_t = 0;
     m->drop_step = 0;
     return DCV_OK;
@@ -1197,7 +1272,7 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         DCV_REQUIRE(desc->act[l] >= DCV_ACT_NONE && desc->act[l] <= DCV_ACT_CUSTOM_SIGMOID, "dcv_mlp_create: act[%d]=%d unsupported", l, desc->act[l]);
     for (int l = 0; l < L; ++l)
         DCV_REQUIRE(desc->dropout[l] >= 0.f && desc->dropout[l] < 1.f, "dcv_mlp_create: dropout[%d]=%g outside [0, 1)", l, (double)desc->dropout[l]);
-    DCV_REQUIRE(desc->optimizer >= DCV_OPT_ADAM && desc->optimizer <= DCV_OPT_ADAGRAD, "dcv_mlp_create: optimizer %d unknown", desc->optimizer);
+    DCV_REQUIRE(desc->optimizer >= DCV_OPT_ADAM && desc->optimizer <= DCV_OPT_RPROP, "dcv_mlp_create: optimizer %d unknown", desc->optimizer);
     DCV_REQUIRE(desc->max_batch >= 1, "dcv_mlp_create: max_batch=%d", desc->max_batch);
     if (desc->model == DCV_MODEL_DEEPTICA) {
         DCV_REQUIRE(desc->dims[L] <= kMaxTicaDim, "dcv_mlp_create: Deep-TICA output dimension %d > %d", desc->dims[L], kMaxTicaDim);
@@ -1218,8 +1293,10 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->adam_t = 0;
     m->last_batch = 0;
     m->opt_aux = nullptr;
-    m->momentum_rt = (desc->optimizer == DCV_OPT_ADAM || desc->optimizer == DCV_OPT_ADAMW) ? desc->beta1 : desc->momentum;
+    m->momentum_rt = (desc->optimizer == DCV_OPT_ADAM || desc->optimizer == DCV_OPT_ADAMW || desc->optimizer == DCV_OPT_ADAMAX ||
+                      desc->optimizer == DCV_OPT_NADAM || desc->optimizer == DCV_OPT_RADAM) ? desc->beta1 : desc->momentum;
     m->any_drop = false;
+    m->any_bn = false;
     for (int l = 0; l < L; ++l) m->any_drop = m->any_drop || desc->dropout[l] > 0.f;
     m->fwd_train = false;
     m->head_done = false;
@@ -1250,6 +1327,17 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         off += align_up((size_t)p.in * p.out, 4);
         p.b_off = off;
         off += align_up((size_t)p.out, 4);
+        p.bn = desc->batchnorm[l] ? 1 : 0;
+        p.g_off = p.be_off = -1;
+        p.Y = nullptr; p.rm = p.rv = nullptr; p.bn_stat = p.bn_part = nullptr; p.bn_gpart = p.bn_bpart = nullptr;
+        p.bn_batches = 0;
+        if (p.bn) {
+            p.g_off = off;
+            off += align_up((size_t)p.out, 4);
+            p.be_off = off;
+            off += align_up((size_t)p.out, 4);
+            m->any_bn = true;
+        }
         p.ldh = align_up((size_t)p.out, 4);
         if (p.out > maxdim) maxdim = p.out;
         wgrad_plan(p.out, p.in, m->rows_cap, &p.k_chunk_cap, &p.max_splits);
@@ -1264,6 +1352,16 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         rc = dmalloc(&p.H, (size_t)m->rows_cap * p.ldh);
         if (rc == DCV_OK) rc = dmalloc(&p.slab, (size_t)p.max_splits * p.in * p.out);
         if (rc == DCV_OK) rc = dmalloc(&p.bpart, (size_t)cdiv(m->rows_cap, 32) * p.out);  // row tiles of the dgrad epilogue can be as short as 32
+        if (rc == DCV_OK && p.bn) {
+            const size_t nblk = (size_t)cdiv(m->rows_cap, 256) + 2;
+            rc = dmalloc(&p.Y, (size_t)m->rows_cap * p.ldh);
+            if (rc == DCV_OK) rc = dmalloc(&p.rm, (size_t)p.out);
+            if (rc == DCV_OK) rc = dmalloc(&p.rv, (size_t)p.out);
+            if (rc == DCV_OK) rc = dmalloc(&p.bn_stat, (size_t)4 * p.out);
+            if (rc == DCV_OK) rc = dmalloc(&p.bn_part, nblk * 2 * p.out);
+            if (rc == DCV_OK) rc = dmalloc(&p.bn_gpart, nblk * p.out);
+            if (rc == DCV_OK) rc = dmalloc(&p.bn_bpart, nblk * p.out);
+        }
         p.mask = nullptr;
         p.mask_rows = -1;
         if (rc == DCV_OK && l + 1 < L && (p.act == DCV_ACT_RELU || p.act == DCV_ACT_LEAKY_RELU))   // one bit per element, whole tiles
@@ -1316,6 +1414,11 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
         for (int i = 0; i < dl; ++i) eye[(size_t)i * dl + i] = 1.f;
         e = hipMemcpy(m->ident, eye.data(), eye.size() * sizeof(float), hipMemcpyHostToDevice);
     }
+    if (e == hipSuccess) {
+        for (auto& p : m->layers)
+            if (p.bn) hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, 0, m->params + p.g_off, (int64_t)p.out, 1.f);   // BatchNorm1d: weight 1, bias 0
+        if (reset_bn_state(m, nullptr) != DCV_OK) e = hipErrorUnknown;
+    }
     if (e == hipSuccess) (void)alloc_tail_ws(&m->tail, 8);   // up to 8 column tiles; on failure the tail cut stays off
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
@@ -1331,6 +1434,8 @@ extern "C" void dcv_mlp_destroy(dcv_mlp* m) { mlp_free(m); }
 extern "C" int64_t dcv_mlp_num_params(const dcv_mlp* m) { return m ? m->n_params : 0; }
 extern "C" int64_t dcv_mlp_param_offset(const dcv_mlp* m, int32_t layer, int32_t which) {
     if (!m || layer < 0 || layer >= m->L) return -1;
+    if (which == 2) return m->layers[layer].g_off;    // weight / bias of the batch normalisation behind the layer, -1 without one
+    if (which == 3) return m->layers[layer].be_off;
     return which == 0 ? m->layers[layer].w_off : m->layers[layer].b_off;
 }
 extern "C" float* dcv_mlp_params(dcv_mlp* m) { return m ? m->params : nullptr; }
@@ -1339,11 +1444,24 @@ extern "C" double* dcv_mlp_stats(dcv_mlp* m) { return m ? m->stats : nullptr; }
 extern "C" int32_t dcv_mlp_stats_len(const dcv_mlp* m) { return m ? m->stats_len : 0; }
 extern "C" int32_t dcv_mlp_log_width(const dcv_mlp* m) { return m ? m->log_width : 0; }
 
+// running statistics of a freshly constructed BatchNorm1d: mean 0, variance 1, no batches tracked
+static int reset_bn_state(dcv_mlp* m, hipStream_t s) {
+    for (auto& p : m->layers) {
+        if (!p.bn) continue;
+        DCV_CHECK_HIP(hipMemsetAsync(p.rm, 0, (size_t)p.out * sizeof(float), s));
+        hipLaunchKernelGGL(fill_kernel, dim3(1), dim3(256), 0, s, p.rv, (int64_t)p.out, 1.f);
+        DCV_CHECK_LAUNCH();
+        p.bn_batches = 0;
+    }
+    return DCV_OK;
+}
+
 extern "C" int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* stream) {
     DCV_REQUIRE(m && params_h, "dcv_mlp_set_params: null argument");
     hipStream_t s = as_stream(stream);
     DCV_CHECK_HIP(hipMemcpyAsync(m->params, params_h, m->n_params * sizeof(float), hipMemcpyHostToDevice, s));
     int rc = reset_opt_state(m, s);
+    if (rc == DCV_OK) rc = reset_bn_state(m, s);
     if (rc) return rc;
     DCV_CHECK_HIP(hipStreamSynchronize(s));
     return DCV_OK;
@@ -1353,6 +1471,26 @@ extern "C" int dcv_mlp_get_params(dcv_mlp* m, float* params_h, void* stream) {
     DCV_REQUIRE(m && params_h, "dcv_mlp_get_params: null argument");
     hipStream_t s = as_stream(stream);
     DCV_CHECK_HIP(hipMemcpyAsync(params_h, m->params, m->n_params * sizeof(float), hipMemcpyDeviceToHost, s));
+    DCV_CHECK_HIP(hipStreamSynchronize(s));
+    return DCV_OK;
+}
+
+extern "C" int dcv_mlp_bn_state(dcv_mlp* m, int32_t layer, float* running_mean_h, float* running_var_h, int64_t* num_batches_tracked,
+                                int32_t set, void* stream) {
+    DCV_REQUIRE(m && layer >= 0 && layer < m->L && running_mean_h && running_var_h && num_batches_tracked, "dcv_mlp_bn_state: bad arguments");
+    LayerPlan& p = m->layers[layer];
+    DCV_REQUIRE(p.bn, "dcv_mlp_bn_state: layer %d has no batch normalisation", layer);
+    hipStream_t s = as_stream(stream);
+    const size_t bytes = (size_t)p.out * sizeof(float);
+    if (set) {
+        DCV_CHECK_HIP(hipMemcpyAsync(p.rm, running_mean_h, bytes, hipMemcpyHostToDevice, s));
+        DCV_CHECK_HIP(hipMemcpyAsync(p.rv, running_var_h, bytes, hipMemcpyHostToDevice, s));
+        p.bn_batches = *num_batches_tracked;
+    } else {
+        DCV_CHECK_HIP(hipMemcpyAsync(running_mean_h, p.rm, bytes, hipMemcpyDeviceToHost, s));
+        DCV_CHECK_HIP(hipMemcpyAsync(running_var_h, p.rv, bytes, hipMemcpyDeviceToHost, s));
+        *num_batches_tracked = p.bn_batches;
+    }
     DCV_CHECK_HIP(hipStreamSynchronize(s));
     return DCV_OK;
 }
@@ -1462,10 +1600,13 @@ static bool act_mask_enabled() {
 // layer l + 1 can ride in the epilogue of layer l: it is narrow and layer l's output fits one column tile
 static bool next_layer_fusable(const dcv_mlp* m, int l) {
     static const bool off = [] { const char* e = getenv("DCV_NO_HEAD_FUSION"); return e && e[0] == '1'; }();
-    if (off || l + 1 >= m->L) return false;
+    if (off || l + 1 >= m->L || m->any_bn) return false;
     if (m->desc.dropout[l + 1] > 0.f) return false;
     return m->layers[l + 1].out <= 8 && m->layers[l].out <= 128;
 }
+
+// what the layer behind Linear l hands on: the batch-normalised values when it has a normalisation, else the activations
+static inline float* layer_out(const dcv_mlp* m, int l) { return m->layers[l].bn ? m->layers[l].Y : m->layers[l].H; }
 
 // forward through layers [0, n_run) for `rows` logical rows
 // (dropout follows m->fwd_train, which the callers set: training forward on, everything else off)
@@ -1474,7 +1615,7 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
     for (int l = 0; l < n_run; ++l) {
         LayerPlan& p = m->layers[l];
         p.mask_rows = -1;
-        Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
+        Operand A = l == 0 ? make_operand(Xn, ld, p.in, rows_map) : make_operand(layer_out(m, l - 1), m->layers[l - 1].ldh, p.in);
         Operand B = make_operand(m->params + p.w_off, p.in, p.in);
         if (l + 1 < n_run && next_layer_fusable(m, l)) {
             // the narrow Linear behind this layer rides in its epilogue (the whole row of H is in the workgroup)
@@ -1505,8 +1646,24 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             p.mask_rows = rows;
         }
         prof_mark(m, l, 0, 0, s);
-        const int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
+        if (p.bn) {   // the derivative of the normalised layer needs the activations themselves, not their signs
+            epi.mask = nullptr;
+            p.mask_rows = -1;
+        }
+        int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
         if (rc) return rc;
+        if (p.bn) {
+            // training: batch statistics of every forward call of the step -- a Deep-TICA batch is two (x_t rows, then x_lag
+            // rows), each normalised by its own statistics and each updating the running ones; evaluation: running statistics
+            const bool train = m->fwd_train && for_backward;
+            if (train && rows_map.half > 0) {
+                rc = bn_forward(m, l, 0, rows_map.half, true, s);
+                if (rc == DCV_OK) rc = bn_forward(m, l, rows_map.half, rows - rows_map.half, true, s);
+            } else {
+                rc = bn_forward(m, l, 0, rows, train, s);
+            }
+            if (rc) return rc;
+        }
         prof_mark(m, l, 0, 1, s);
     }
     return DCV_OK;
@@ -1583,6 +1740,7 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
     int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s, fuse_head != 2);   // the one-GPU evaluation step has no backward: no sign masks
     if (rc) return rc;
     const LayerPlan& last = m->layers[m->L - 1];
+    const float* net_out = layer_out(m, m->L - 1);   // the network's output: behind the last layer's normalisation when it has one
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
         int nb;
         if (tica_stats_fn_t fast = tica_stats_rows_fn(m->d_out)) {
@@ -1593,7 +1751,7 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
                 DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
                 fh = FusedHead{1, (double)batch, m->desc.tica_reg, fuse_head == 1 ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width};
             }
-            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, (const float*)last.H, last.ldh, (int)batch, lag_offset(m, idx_d, batch), rpb,
+            hipLaunchKernelGGL(fast, dim3(nb), dim3(256), 0, s, net_out, last.ldh, (int)batch, lag_offset(m, idx_d, batch), rpb,
                                m->spart, m->ticket, m->stats, fh);
             DCV_CHECK_LAUNCH();
             m->last_batch = batch;
@@ -1601,7 +1759,7 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
             return DCV_OK;
         } else {
             nb = (int)cdiv(batch, kStatBlockRows);
-            hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, last.H,
+            hipLaunchKernelGGL(tica_stats_kernel, dim3(nb), dim3(256), (size_t)2 * kStatBlockRows * m->d_out * sizeof(double), s, net_out,
                                last.ldh, batch, m->d_out, lag_offset(m, idx_d, batch), m->spart);
         }
         DCV_CHECK_LAUNCH();
@@ -1622,12 +1780,12 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
         const int nb = (int)cdiv(R, rpb);
         if (fuse_head) {   // one-GPU step: final sum and loss record in the last block of the same launch
             DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
-            hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
+            hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, net_out, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
                                m->ticket, m->stats, (double)batch, m->log, m->log_count, m->log_cap, m->log_width, (int)rpb);
             DCV_CHECK_LAUNCH();
             m->head_done = true;
         } else {
-            hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
+            hipLaunchKernelGGL(ae_sse_kernel, dim3(nb), dim3(256), 0, s, net_out, last.ldh, Xn_d, ld, rm, R, m->desc.dims[0], m->feat_range, m->spart,
                                (unsigned*)nullptr, (double*)nullptr, 0.0, (double*)nullptr, (int*)nullptr, 0, 0, (int)rpb);
             DCV_CHECK_LAUNCH();
             hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(64), 0, s, m->spart, nb, 1, m->stats);
@@ -1642,15 +1800,18 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
 // optimiser update fused in.
 static int launch_reduce(dcv_mlp* m, const ReduceArgs& ra_all, int l0, int l1, bool fuse_opt, const OptArgs& oa, hipStream_t s) {
     ReduceArgs ra;
-    ra.L = l1 - l0;
+    ra.L = 0;
     int max_splits = 0, max_bblocks = 0;
     int64_t max_total = 0;
-    for (int l = l0; l < l1; ++l) {
-        ra.l[l - l0] = ra_all.l[l];
-        if (ra_all.l[l].splits > max_splits) max_splits = ra_all.l[l].splits;
-        if (ra_all.l[l].bblocks > max_bblocks) max_bblocks = ra_all.l[l].bblocks;
-        if (ra_all.l[l].w_count + ra_all.l[l].out > max_total) max_total = ra_all.l[l].w_count + ra_all.l[l].out;
-    }
+    auto take = [&](const ReduceDesc& d) {
+        ra.l[ra.L++] = d;
+        if (d.splits > max_splits) max_splits = d.splits;
+        if (d.bblocks > max_bblocks) max_bblocks = d.bblocks;
+        if (d.w_count + d.out > max_total) max_total = d.w_count + d.out;
+    };
+    for (int l = l0; l < l1; ++l) take(ra_all.l[l]);
+    for (int l = l0; l < l1; ++l)
+        if (m->layers[l].bn) take(ra_all.l[m->L + l]);   // weight / bias of the batch normalisation behind layer l
     if (ra.L <= 0) return DCV_OK;
     if (max_splits <= 512 && max_bblocks <= 1024) {   // few partials per weight (the few bias elements may see more)
         int64_t bx = cdiv(max_total, 64);
@@ -1684,6 +1845,12 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     const int64_t R = rows_of(m, idx_d, batch);
     const int L = m->L;
     const LayerPlan& last = m->layers[L - 1];
+    // a normalised last layer: the loss gradient is taken w.r.t. the normalised output; activation derivative and dropout
+    // of the Linear underneath are applied by the normalisation's backward pass
+    const float* net_out = layer_out(m, L - 1);
+    const int last_act = last.bn ? DCV_ACT_NONE : last.act;
+    const DropCfg last_drop = last.bn ? kNoDrop : drop_cfg(m, L - 1);
+    const float last_hscale = last.bn ? 1.f : drop_hscale(m, L - 1);
     float* dz_cur = m->dZ[0];
     float* dz_nxt = m->dZ[1];
     bool fused_head = false;
@@ -1697,8 +1864,8 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         if (!train) return DCV_OK;
         fused_head = head_fusable(m);
         if (!fused_head) {
-            hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, last.H, last.ldh, batch, m->d_out,
-                               lag_offset(m, idx_d, batch), m->gradp, last.act, dz_cur, m->ld_dz, drop_cfg(m, L - 1), drop_hscale(m, L - 1));
+            hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, net_out, last.ldh, batch, m->d_out,
+                               lag_offset(m, idx_d, batch), m->gradp, last_act, dz_cur, m->ld_dz, last_drop, last_hscale);
             DCV_CHECK_LAUNCH();
         }
     } else {
@@ -1713,16 +1880,16 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         int64_t blocks = cdiv(R * F, 256);
         const int64_t cap = (int64_t)num_cus() * 16;
         if (blocks > cap) blocks = cap;
-        hipLaunchKernelGGL(ae_dY_kernel, dim3((unsigned)blocks), dim3(256), 0, s, last.H, last.ldh, Xn_d, ld, rm, R, F, m->feat_range, scale,
-                           last.act, dz_cur, m->ld_dz, drop_cfg(m, L - 1), drop_hscale(m, L - 1));
+        hipLaunchKernelGGL(ae_dY_kernel, dim3((unsigned)blocks), dim3(256), 0, s, net_out, last.ldh, Xn_d, ld, rm, R, F, m->feat_range, scale,
+                           last_act, dz_cur, m->ld_dz, last_drop, last_hscale);
         DCV_CHECK_LAUNCH();
     }
-    ReduceArgs ra;
+    ReduceArgs ra{};
     ra.L = L;
     // bias-gradient partials of the last layer come from a column-sum pass over dZ_last; those of
     // every other layer fall out of the dgrad epilogue that produces its dZ
     int bblocks = (int)cdiv(R, kColsumRows);
-    if (!fused_head) {
+    if (!fused_head && !last.bn) {
         hipLaunchKernelGGL(colsum_kernel, dim3(bblocks), dim3(256), 0, s, dz_cur, R, last.out, m->ld_dz, m->layers[L - 1].bpart);
         DCV_CHECK_LAUNCH();
     }
@@ -1737,6 +1904,25 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             if (rcu) return rcu;
             upper_done = true;
             m->upper_cb(m->upper_cb_user);
+        }
+        if (p.bn) {
+            // dz_cur holds dL/d(normalised output): back through the normalisation, the dropout and the activation of this
+            // layer, in place; its passes also leave the gradient partials of the normalisation's weight / bias and the
+            // bias-gradient partials of this Linear
+            const bool two = rm.half > 0;   // two forward calls (x_t rows, x_lag rows), each with its own statistics
+            int nb = 0;
+            int rcb = bn_backward(m, l, dz_cur, m->ld_dz, two ? 2 : 1, two ? (int64_t)rm.half : R, p.act, drop_hscale(m, l), drop_cfg(m, l), &nb, s);
+            if (rcb) return rcb;
+            bblocks = nb;
+            ReduceDesc& bd = ra.l[L + l];
+            bd.slab = p.bn_gpart;
+            bd.bpart = p.bn_bpart;
+            bd.w_off = p.g_off;
+            bd.b_off = p.be_off;
+            bd.w_count = p.out;
+            bd.out = p.out;
+            bd.splits = nb;
+            bd.bblocks = nb;
         }
         // wgrad: dW = dZ^T In  (M = out, N = in, K = rows)
         int64_t kc, splits;
@@ -1776,7 +1962,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             continue;
         }
         Operand A = make_operand(dz_cur, m->ld_dz, p.out);
-        Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(m->layers[l - 1].H, m->layers[l - 1].ldh, p.in);
+        Operand B = l == 0 ? make_operand(Xn_d, ld, p.in, rm) : make_operand(layer_out(m, l - 1), m->layers[l - 1].ldh, p.in);
         EpiSlab epi{p.slab, p.out, p.in, 1, 0, quad_ok(p.slab, p.in), p.max_splits};
         ReduceDesc& rd = ra.l[l];
         rd.slab = p.slab;
@@ -1805,6 +1991,12 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         }
         eg.drop = drop_cfg(m, l - 1);
         eg.hscale = drop_hscale(m, l - 1);
+        if (q.bn) {   // a normalised layer below: hand down the raw product dL/d(its normalised output); bn_backward does the rest
+            eg.act = DCV_ACT_NONE;
+            eg.mask = nullptr;
+            eg.drop = kNoDrop;
+            eg.hscale = 1.f;
+        }
         // the two products read the same dZ and neither reads the other's output: one launch when the pair form applies
         prof_mark(m, l, 1, 0, s);
         prof_mark(m, l, 2, 0, s);
@@ -1889,6 +2081,7 @@ static OptArgs next_opt_args(dcv_mlp* m) {
     a.first = m->adam_t == 1;
     a.lr = (float)m->lr;
     a.b1 = a.b2 = a.c1 = a.c2 = a.w1 = a.w2 = 0.f;
+    a.p0 = a.p1 = a.p2 = a.p3 = 0.f;
     a.decay = 1.f;
     a.eps = (float)d.eps;
     a.wd = (float)d.weight_decay;
@@ -1917,6 +2110,66 @@ static OptArgs next_opt_args(dcv_mlp* m) {
             a.b2 = (float)d.alpha;
             a.w2 = (float)(1.0 - d.alpha);
             break;
+        case DCV_OPT_ADAMAX: {
+            const double b1 = m->momentum_rt;
+            a.b1 = (float)b1;
+            a.b2 = (float)d.beta2;
+            a.w1 = (float)(1.0 - b1);
+            a.c1 = (float)(m->lr / (1.0 - pow(b1, t)));
+            break;
+        }
+        case DCV_OPT_NADAM: {
+            const double b1 = m->momentum_rt, b2 = d.beta2, md = d.opt_p[0];
+            a.flag = d.opt_p[1] != 0.0 ? 1 : 0;
+            a.b1 = (float)b1;
+            a.b2 = (float)b2;
+            a.w1 = (float)(1.0 - b1);
+            a.w2 = (float)(1.0 - b2);
+            a.c2 = (float)(1.0 - pow(b2, t));
+            a.decay = (float)(1.0 - m->lr * d.weight_decay);
+            const double mu = b1 * (1.0 - 0.5 * pow(0.96, t * md));
+            const double mu_next = b1 * (1.0 - 0.5 * pow(0.96, (t + 1.0) * md));
+            // the state tensor mu_product is float32: `mu_product *= mu`, then read back through .item()
+            m->nadam_mu_product = (double)(float)((double)(float)m->nadam_mu_product * mu);
+            const double mp = m->nadam_mu_product, mp_next = mp * mu_next;
+            a.p0 = (float)(-m->lr * (1.0 - mu) / (1.0 - mp));
+            a.p1 = (float)((-m->lr * mu_next) / (1.0 - mp_next));
+            break;
+        }
+        case DCV_OPT_RADAM: {
+            const double b1 = m->momentum_rt, b2 = d.beta2;
+            a.flag = d.opt_p[1] != 0.0 ? 1 : 0;
+            a.b1 = (float)b1;
+            a.b2 = (float)b2;
+            a.w1 = (float)(1.0 - b1);
+            a.w2 = (float)(1.0 - b2);
+            a.decay = (float)(1.0 - m->lr * d.weight_decay);
+            const double bc1 = 1.0 - pow(b1, t), bc2 = 1.0 - pow(b2, t);
+            a.c1 = (float)bc1;
+            a.c2 = (float)sqrt(bc2);
+            const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+            const double rho_t = rho_inf - 2.0 * t * pow(b2, t) / bc2;
+            a.p0 = rho_t > 5.0 ? (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t)) : 0.f;
+            break;
+        }
+        case DCV_OPT_ADADELTA:
+            a.b2 = (float)d.opt_p[0];
+            a.w2 = (float)(1.0 - d.opt_p[0]);
+            break;
+        case DCV_OPT_ASGD: {
+            // eta is a float32 state tensor: written as lr / (1 + lambd lr step)^alpha after every step, read back through .item()
+            const double eta = m->asgd_eta;
+            a.p0 = (float)(1.0 - d.opt_p[0] * eta);
+            a.p1 = (float)eta;
+            m->asgd_eta = (double)(float)(m->lr / pow(1.0 + d.opt_p[0] * m->lr * t, d.opt_p[1]));
+            break;
+        }
+        case DCV_OPT_RPROP:
+            a.p0 = (float)d.opt_p[0];
+            a.p1 = (float)d.opt_p[1];
+            a.p2 = (float)d.opt_p[2];
+            a.p3 = (float)d.opt_p[3];
+            break;
         default:   // DCV_OPT_ADAGRAD
             a.c1 = (float)(m->lr / (1.0 + (t - 1.0) * d.lr_decay));
             break;
@@ -1939,7 +2192,7 @@ static int apply_impl(dcv_mlp* m, void* stream) {
 // One-GPU autoencoder step as ONE fused launch (+ the gradient reduction with the optimiser update) when the network
 // fits in LDS (snet.hip); 1 = not applicable: the caller runs the layer-by-layer path.
 static int snet_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int32_t train, void* stream) {
-    if (m->desc.model != DCV_MODEL_AE || m->any_drop || (m->snet_tried && m->snet == nullptr)) return 1;
+    if (m->desc.model != DCV_MODEL_AE || m->any_drop || m->any_bn || (m->snet_tried && m->snet == nullptr)) return 1;
     if (!(Xn_d && batch >= 1 && batch <= m->desc.max_batch && ld >= m->desc.dims[0] && m->log && m->log_cap > 0)) return 1;   // the general path reports it
     hipStream_t s = as_stream(stream);
     const RowMap rm = RowMap{idx_d, row0, 0, 0};
@@ -2088,7 +2341,7 @@ extern "C" int dcv_mlp_infer(dcv_mlp* m, const float* Xn_d, int64_t n, int64_t l
     const LayerPlan& last = m->layers[n_run - 1];
     const int d = last.out;
     // y = (h - tmean) @ tevecs ; out = (y - pmean) / prange   -- the linear projection kernel
-    return dcv_project_linear(last.H, n, d, last.ldh, tmean_d ? tmean_d : m->zeros_d, m->ones_d, tevecs_d ? tevecs_d : m->ident, d,
+    return dcv_project_linear(layer_out(m, n_run - 1), n, d, last.ldh, tmean_d ? tmean_d : m->zeros_d, m->ones_d, tevecs_d ? tevecs_d : m->ident, d,
                               nullptr, pmean_d, prange_d, out_d, minmax_d, m->proj_ws, m->proj_ws_bytes, stream);
 }
 
@@ -2119,18 +2372,26 @@ extern "C" int dcv_mlp_input_sensitivity(dcv_mlp* m, const float* Xn_d, int64_t 
     const LayerPlan& last = m->layers[n_run - 1];
     float* dz_cur = m->dZ[0];
     float* dz_nxt = m->dZ[1];
-    hipLaunchKernelGGL(seed_grad_kernel, dim3((unsigned)cdiv(n * last.out, 256)), dim3(256), 0, s, last.H, last.ldh, n, last.out, last.act,
-                       gout_d, dz_cur, m->ld_dz);
+    hipLaunchKernelGGL(seed_grad_kernel, dim3((unsigned)cdiv(n * last.out, 256)), dim3(256), 0, s, (const float*)layer_out(m, n_run - 1), last.ldh, n,
+                       last.out, last.bn ? DCV_ACT_NONE : last.act, gout_d, dz_cur, m->ld_dz);
     DCV_CHECK_LAUNCH();
+    if (last.bn) {   // evaluation-mode normalisation: a per-column scale, then the activation derivative of the Linear underneath
+        rc = bn_eval_backward(m, n_run - 1, dz_cur, m->ld_dz, n, last.act, s);
+        if (rc) return rc;
+    }
     for (int l = n_run - 1; l >= 1; --l) {   // dZ_{l-1} = (dZ_l W_l) * act'(H_{l-1})
         LayerPlan& p = m->layers[l];
         LayerPlan& q = m->layers[l - 1];
         Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
         Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
-        EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
+        EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.bn ? DCV_ACT_NONE : q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
         int bblocks = 0;
         rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, n, p.in, p.out, 0, eg, s, &bblocks);
         if (rc) return rc;
+        if (q.bn) {
+            rc = bn_eval_backward(m, l - 1, dz_nxt, m->ld_dz, n, q.act, s);
+            if (rc) return rc;
+        }
         float* tmp = dz_cur;
         dz_cur = dz_nxt;
         dz_nxt = tmp;

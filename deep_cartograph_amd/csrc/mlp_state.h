@@ -19,6 +19,15 @@ struct LayerPlan {
     float* bpart;              // [bias_blocks_cap][out]
     unsigned long long* mask;  // sign mask of H in the forward epilogue's thread layout (ReLU family), or null
     int64_t mask_rows;         // row count of the training forward that wrote it (-1: stale)
+    // batch normalisation behind this Linear (bn.hip), or bn == 0
+    int bn;
+    int64_t g_off, be_off;     // weight / bias of the normalisation in the flat parameter buffer
+    float* Y;                  // [rows][ldh] normalised output (input of the next layer); H keeps the values it was computed from
+    float *rm, *rv;            // running mean / variance [out]
+    double* bn_stat;           // [2 forward calls][mean | invstd][out] of the last training forward
+    double* bn_part;           // statistics partials [blocks][2][out]
+    float *bn_gpart, *bn_bpart;   // gradient partials of weight / bias [blocks][out]
+    int64_t bn_batches;        // num_batches_tracked
 };
 
 }  // namespace dcv
@@ -33,7 +42,10 @@ struct dcv_mlp {
     float *params, *grads, *adam_m, *adam_v;
     float* opt_aux;            // third optimiser state (amsgrad maximum / centred RMSprop gradient average) or null
     double momentum_rt;        // beta1 (Adam family) or momentum (SGD, RMSprop): dcv_mlp_set_momentum
+    double nadam_mu_product;   // NAdam: the float32 state mu_product, as torch reads it back
+    double asgd_eta;           // ASGD: the float32 state eta
     bool any_drop;             // some layer has dropout p > 0
+    bool any_bn;               // some layer is followed by a batch normalisation
     bool fwd_train;            // the last forward ran in training mode (dropout active): backward must agree
     dcv::TailWs tail;          // workspace of the contraction-split tail tile of row-tiled products (gemm.h: GemmDims::tail_split)
     void (*upper_cb)(void*);   // data-parallel overlap hook (dcv_mlp_set_upper_grads_callback) or null
@@ -89,4 +101,9 @@ struct ReduceArgsView {
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int32_t batch, int train, ReduceArgsView* ra,
                  hipStream_t s);
 void snet_free(dcv_mlp* m);
+// bn.hip
+int bn_forward(dcv_mlp* m, int l, int64_t row0, int64_t rows, bool train, hipStream_t s);
+int bn_backward(dcv_mlp* m, int l, float* dz, int64_t ld_dz, int halves, int64_t rows_half, int act, float hscale, const DropCfg& drop,
+                int* blocks_out, hipStream_t s);
+int bn_eval_backward(dcv_mlp* m, int l, float* dz, int64_t ld_dz, int64_t rows, int act, hipStream_t s);
 }  // namespace dcv

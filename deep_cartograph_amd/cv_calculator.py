@@ -600,7 +600,18 @@ _OPTIMIZERS = {
     "SGD": dict(lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False),
     "RMSprop": dict(lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False),
     "Adagrad": dict(lr=1e-2, lr_decay=0.0, weight_decay=0.0, initial_accumulator_value=0.0, eps=1e-10),
+    "Adamax": dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0),
+    "NAdam": dict(lr=2e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, momentum_decay=4e-3, decoupled_weight_decay=False),
+    "RAdam": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled_weight_decay=False),
+    "Adadelta": dict(lr=1.0, rho=0.9, eps=1e-6, weight_decay=0.0),
+    "ASGD": dict(lr=1e-2, lambd=1e-4, alpha=0.75, t0=1e6, weight_decay=0.0),
+    "Rprop": dict(lr=1e-2, etas=(0.5, 1.2), step_sizes=(1e-6, 50.0)),
 }
+# torch.optim classes the reference's `getattr(torch.optim, name)` would also accept and the engine does not run:
+# LBFGS re-evaluates the loss through a closure several times per step (not a per-element update), SparseAdam rejects
+# the dense gradients of these models inside torch itself (the reference's try fails there too)
+_OPTIMIZERS_REFUSED = {"LBFGS": "needs a closure that re-evaluates the model several times per step",
+                       "SparseAdam": "torch.optim.SparseAdam does not support dense gradients (the reference's try fails as well)"}
 _IMPLEMENTATION_SWITCHES = ("foreach", "fused", "capturable", "differentiable")   # no effect on the arithmetic
 
 
@@ -724,13 +735,10 @@ class NonLinear(CVCalculator):
         act.append(cfg.get("last_layer_activation", None))
         drop.append(cfg.get("last_layer_dropout", None))
         bn.append(cfg.get("last_layer_batchnorm", False))
-        if any(bn):
-            raise NotImplementedError("batch normalisation layers are not implemented by the HIP engine "
-                                      "(set 'batchnorm' / 'last_layer_batchnorm' to False)")
         drop = [float(d) if d else 0.0 for d in drop]
         if any(d < 0.0 or d >= 1.0 for d in drop):
             raise ValueError("dropout probabilities must lie in [0, 1)")
-        return act, drop
+        return act, drop, [bool(b) for b in bn]
 
     def _optimizer_options(self) -> Tuple[str, Dict]:
         """(torch.optim class name, its keyword arguments with torch's defaults filled in) -- reference :1376-1380."""
@@ -738,7 +746,8 @@ class NonLinear(CVCalculator):
         if name not in _OPTIMIZERS:
             if not hasattr(torch.optim, name):
                 raise ValueError(f"Optimizer {name} not recognized.")
-            raise NotImplementedError(f"optimizer {name} is not implemented by the HIP engine (have: {sorted(_OPTIMIZERS)})")
+            why = _OPTIMIZERS_REFUSED.get(name, "")
+            raise NotImplementedError(f"optimizer {name} is not implemented by the HIP engine{': ' + why if why else ''} (have: {sorted(_OPTIMIZERS)})")
         kw = dict(_OPTIMIZERS[name])
         for k, v in (self.optimizer_config.get("kwargs", {}) or {}).items():
             if k in _IMPLEMENTATION_SWITCHES:
@@ -763,6 +772,16 @@ class NonLinear(CVCalculator):
         for k in ("amsgrad", "nesterov", "centered"):
             if k in kw:
                 out[k] = bool(kw[k])
+        # further constants, in the order of dcv.h's DCV_OPT_* comments
+        extra = {"NAdam": [kw.get("momentum_decay", 4e-3), 1.0 if kw.get("decoupled_weight_decay") else 0.0],
+                 "RAdam": [0.0, 1.0 if kw.get("decoupled_weight_decay") else 0.0],
+                 "Adadelta": [kw.get("rho", 0.9)],
+                 "ASGD": [kw.get("lambd", 1e-4), kw.get("alpha", 0.75), kw.get("t0", 1e6)],
+                 "Rprop": list(kw.get("etas", (0.5, 1.2))) + list(kw.get("step_sizes", (1e-6, 50.0)))}.get(name)
+        if extra is not None:
+            out["opt_params"] = [float(v) for v in extra]
+        if name == "ASGD":
+            out.pop("alpha", None)   # ASGD's alpha is the eta exponent (opt_params), not RMSprop's smoothing constant
         return out
 
     def _scheduler_options(self, steps_per_epoch: int) -> Optional[Tuple[str, Dict, Dict]]:
@@ -934,7 +953,7 @@ class NonLinear(CVCalculator):
         self.cv = best["state"]
         self.cv_score = best["score"]
         self.metrics = best["metrics"]
-        self.engine.set_linears(self.cv["linears"])
+        self.engine.set_linears(self.cv["linears"], bn=self.cv.get("bn"))
         logger.info(f"Best model score across {self.num_tries} tries: {best['score']:.5f}")
         return True
 
@@ -969,6 +988,7 @@ class NonLinear(CVCalculator):
         nmax = max(1, min(bs, max(n_tr, n_va)))
         self.engine = hip.Mlp(self.model_kind, dims, acts, max_batch=nmax, lag=self.lag(), latent_layer=latent,
                               tica_reg=float(self.configuration.get("tica_regularization", 1e-6)), dropout=drops, seed=seed, device=dev,
+                              batchnorm=getattr(self, "_bn_plan", None),
                               **self._engine_optimizer_kwargs(opt_name, opt_kw))
         self.engine.set_linears(linears)
         self.engine.set_rank(self.comm.rank)   # data-parallel ranks hold the same seed: independent dropout masks per rank
@@ -1017,7 +1037,8 @@ class NonLinear(CVCalculator):
                     for i, v in enumerate(eig):
                         metrics.setdefault(f"valid_eigval_{i + 1}", []).append(float(v))
                 if (epoch + 1) % self.save_check_every_n_epoch == 0:  # ModelCheckpoint(save_top_k=1, save_last=True)
-                    state = {"linears": self.engine.get_linears(), "tica": buffers, "dims": dims, "acts": acts, "drops": drops, "latent": latent}
+                    state = {"linears": self.engine.get_linears(), "tica": buffers, "dims": dims, "acts": acts, "drops": drops, "latent": latent,
+                             "bn": self.engine.get_bn() if any(getattr(self, "_bn_plan", None) or []) else None}
                     last_state = state
                     if valid_loss < best_score:
                         best_score, best_state = valid_loss, state
@@ -1192,8 +1213,12 @@ class NonLinear(CVCalculator):
         self.cv = {"linears": parts["linears"], "acts": parts["acts"], "dims": dims, "tica": parts["tica"],
                    "post": parts["postprocessing"], "norm_in": parts["norm_in"], "latent": len(parts["linears"])}
         # projection only needs the chain up to the CV (the AE file's encoder): a plain Linear chain
-        self.engine = hip.Mlp("deep_tica", dims, parts["acts"], max_batch=32768, lag=0, device=_device())
-        self.engine.set_linears(parts["linears"])
+        bn = parts.get("bn")
+        has_bn = bn is not None and any(b is not None for b in bn)
+        self.cv["bn"] = bn if has_bn else None
+        self.engine = hip.Mlp("deep_tica", dims, parts["acts"], max_batch=32768, lag=0, device=_device(),
+                              batchnorm=[b is not None for b in bn] if has_bn else None)
+        self.engine.set_linears(parts["linears"], bn=bn if has_bn else None)
 
     def get_cv_parameters(self):
         return {"cv_name": self.cv_name, "cv_dimension": self.cv_dimension, "weights_path": self.weights_path}
@@ -1221,9 +1246,10 @@ class AECalculator(NonLinear):
         self.cv_name = "ae"
 
     def layer_plan(self):
-        enc_act, enc_drop = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        enc_act, enc_drop, enc_bn = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
         dec_cfg = self.decoder_config if self.decoder_config is not None else self.encoder_config
-        dec_act, dec_drop = self._layer_options(dec_cfg, len(self.decoder_hidden_layers))
+        dec_act, dec_drop, dec_bn = self._layer_options(dec_cfg, len(self.decoder_hidden_layers))
+        self._bn_plan = enc_bn + dec_bn
         # the decoder output must cover the range of the normalised features (reference :1188-1207)
         if self.feats_norm_mode == "min_max_range1" and dec_act[-1] != "custom_sigmoid":
             logger.warning(f"The last layer activation function of the decoder is set to {dec_act[-1]}, but the features are "
@@ -1254,9 +1280,10 @@ class AECalculator(NonLinear):
         L = st["latent"]
         ne = len(self.encoder_hidden_layers) + 1
         drops = st.get("drops") or [0.0] * len(st["linears"])
-        enc = export.FeedForward(st["linears"][:L], st["acts"][:L], self._export_dropout(self.encoder_config, drops[:L]))
+        bn = st.get("bn") or [None] * len(st["linears"])
+        enc = export.FeedForward(st["linears"][:L], st["acts"][:L], self._export_dropout(self.encoder_config, drops[:L]), bn[:L])
         dec_cfg = self.decoder_config if self.decoder_config is not None else self.encoder_config
-        dec = export.FeedForward(st["linears"][L:], st["acts"][L:], self._export_dropout(dec_cfg, drops[L:]))
+        dec = export.FeedForward(st["linears"][L:], st["acts"][L:], self._export_dropout(dec_cfg, drops[L:]), bn[L:])
         norm = export.Normalization(self.features_norm_mean, self.features_norm_range) if self.feats_norm_mode is not None else None
         post = export.Normalization(*st["post"]) if st.get("post") is not None else None
         return export.AutoEncoderCV(norm, enc, dec, post)
@@ -1282,7 +1309,8 @@ class DeepTICACalculator(NonLinear):
         return int(self.configuration.get("lag_time"))
 
     def layer_plan(self):
-        act, drop = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        act, drop, bn = self._layer_options(self.encoder_config, len(self.encoder_hidden_layers))
+        self._bn_plan = bn
         dims = [self.num_features] + self.encoder_hidden_layers + [self.cv_dimension]
         return dims, act, drop, len(dims) - 1
 
@@ -1311,7 +1339,7 @@ class DeepTICACalculator(NonLinear):
     def to_torch_module(self):
         st = self.cv
         nl = len(st["linears"])
-        nn_ = export.FeedForward(st["linears"], st["acts"], self._export_dropout(self.encoder_config, st.get("drops") or [0.0] * nl))
+        nn_ = export.FeedForward(st["linears"], st["acts"], self._export_dropout(self.encoder_config, st.get("drops") or [0.0] * nl), st.get("bn"))
         norm = export.Normalization(self.features_norm_mean, self.features_norm_range) if self.feats_norm_mode is not None else None
         tica = export.TICA(st["tica"][1], st["tica"][0])
         post = export.Normalization(*st["post"]) if st.get("post") is not None else None

@@ -53,10 +53,12 @@ class Normalization(torch.nn.Module):
 
 
 class FeedForward(torch.nn.Module):
-    """Linear [, activation][, Dropout] per layer, in the reference's module order."""
+    """Linear [, activation][, Dropout][, BatchNorm1d] per layer, in the reference's module order (mlcolvar FeedForward).
+    ``batchnorm``: per Linear None or the dict of its BatchNorm1d (weight, bias, running_mean, running_var,
+    num_batches_tracked)."""
 
     def __init__(self, linears: Sequence[Tuple[np.ndarray, np.ndarray]], activation: Sequence[Optional[str]],
-                 dropout: Optional[Sequence[Optional[float]]] = None):
+                 dropout: Optional[Sequence[Optional[float]]] = None, batchnorm: Optional[Sequence[Optional[dict]]] = None):
         super().__init__()
         mods: List[torch.nn.Module] = []
         for i, (w, b) in enumerate(linears):
@@ -70,6 +72,16 @@ class FeedForward(torch.nn.Module):
                 mods.append(_ACT_MODULES[act]())
             if dropout is not None and dropout[i] is not None:
                 mods.append(torch.nn.Dropout(p=float(dropout[i])))
+            if batchnorm is not None and batchnorm[i] is not None:
+                st = batchnorm[i]
+                bn = torch.nn.BatchNorm1d(w.shape[0])
+                with torch.no_grad():
+                    bn.weight.copy_(torch.as_tensor(st["weight"], dtype=torch.float32))
+                    bn.bias.copy_(torch.as_tensor(st["bias"], dtype=torch.float32))
+                    bn.running_mean.copy_(torch.as_tensor(st["running_mean"], dtype=torch.float32))
+                    bn.running_var.copy_(torch.as_tensor(st["running_var"], dtype=torch.float32))
+                    bn.num_batches_tracked.fill_(int(st.get("num_batches_tracked", 0)))
+                mods.append(bn)
         self.nn = torch.nn.Sequential(*mods)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -142,21 +154,27 @@ def save_torchscript(model: torch.nn.Module, n_features: int, path: str) -> None
     traced.save(path)
 
 
-def _sequential_layers(seq) -> Tuple[List[Tuple[np.ndarray, np.ndarray]], List[Optional[str]]]:
-    """(linears, activation per linear) from a scripted Sequential of Linear/act/Dropout."""
-    linears, acts = [], []
+def _sequential_layers(seq):
+    """(linears, activation per linear, batch normalisation per linear) from a scripted Sequential of
+    Linear / act / Dropout / BatchNorm1d."""
+    linears, acts, bns = [], [], []
     for child in seq.children():
         name = getattr(child, "original_name", type(child).__name__)
         if name == "Linear":
             linears.append((child.weight.detach().cpu().numpy().copy(), child.bias.detach().cpu().numpy().copy()))
             acts.append(None)
+            bns.append(None)
         elif name in _ACT_FROM_NAME:
             acts[-1] = _ACT_FROM_NAME[name]
         elif name in ("Dropout", "Identity"):
             continue
+        elif name == "BatchNorm1d":
+            st = {k: v.detach().cpu().numpy().copy() for k, v in list(child.named_parameters()) + list(child.named_buffers())}
+            bns[-1] = {"weight": st["weight"], "bias": st["bias"], "running_mean": st["running_mean"], "running_var": st["running_var"],
+                       "num_batches_tracked": int(st.get("num_batches_tracked", 0))}
         else:
             raise ValueError(f"TorchScript layer {name} is not supported by the HIP engine")
-    return linears, acts
+    return linears, acts, bns
 
 
 def read_torchscript(path: str) -> dict:
@@ -176,11 +194,11 @@ def read_torchscript(path: str) -> dict:
     out = {"norm_in": pair("norm_in"), "postprocessing": pair("postprocessing"), "tica": None, "module": m}
     if "nn" in kids and "tica" in kids:
         out["kind"] = "deep_tica"
-        out["linears"], out["acts"] = _sequential_layers(kids["nn"].nn)
+        out["linears"], out["acts"], out["bn"] = _sequential_layers(kids["nn"].nn)
         out["tica"] = (buf["tica.mean"], buf["tica.evecs"])
     elif "encoder" in kids:
         out["kind"] = "ae"
-        out["linears"], out["acts"] = _sequential_layers(kids["encoder"].nn)
+        out["linears"], out["acts"], out["bn"] = _sequential_layers(kids["encoder"].nn)
     else:
         raise ValueError("unrecognised TorchScript CV model (expected a DeepTICA or AutoEncoderCV tree)")
     return out

@@ -317,7 +317,8 @@ class Mlp:
                  latent_layer: Optional[int] = None, lr: float = 1e-3, betas=(0.9, 0.999), eps: Optional[float] = None,
                  weight_decay: float = 0.0, optimizer: str = "Adam", amsgrad: bool = False, momentum: float = 0.0,
                  dampening: float = 0.0, nesterov: bool = False, alpha: float = 0.99, centered: bool = False,
-                 lr_decay: float = 0.0, initial_accumulator_value: float = 0.0, dropout=None, seed: int = 0, device="cuda"):
+                 lr_decay: float = 0.0, initial_accumulator_value: float = 0.0, opt_params=None, dropout=None, seed: int = 0,
+                 batchnorm=None, bn_eps: float = 1e-5, bn_momentum: float = 0.1, device="cuda"):
         import ctypes as C
 
         if not torch.cuda.is_available():
@@ -344,7 +345,7 @@ class Mlp:
         desc.max_batch = int(max_batch)
         desc.tica_reg = float(tica_reg)
         if eps is None:   # torch's default for the optimiser
-            eps = 1e-10 if optimizer == "Adagrad" else 1e-8
+            eps = {"Adagrad": 1e-10, "Adadelta": 1e-6}.get(optimizer, 1e-8)
         desc.lr, desc.beta1, desc.beta2, desc.eps, desc.weight_decay = float(lr), float(betas[0]), float(betas[1]), float(eps), float(weight_decay)
         if optimizer not in _lib.OPTIMIZER:
             raise DcvError(f"optimizer {optimizer!r} is not implemented by the HIP engine (have: {sorted(_lib.OPTIMIZER)})")
@@ -352,6 +353,14 @@ class Mlp:
         desc.amsgrad, desc.nesterov, desc.centered = int(bool(amsgrad)), int(bool(nesterov)), int(bool(centered))
         desc.momentum, desc.dampening, desc.alpha = float(momentum), float(dampening), float(alpha)
         desc.lr_decay, desc.initial_accumulator_value = float(lr_decay), float(initial_accumulator_value)
+        for i, v in enumerate(list(opt_params or [])[:4]):   # further constants of Adamax / NAdam / RAdam / Adadelta / ASGD / Rprop (dcv.h: DCV_OPT_*)
+            desc.opt_p[i] = float(v)
+        self.batchnorm = [bool(b) for b in (batchnorm if batchnorm is not None else [False] * L)]
+        if len(self.batchnorm) != L:
+            raise DcvError("one batchnorm flag per Linear layer expected")
+        for i, b in enumerate(self.batchnorm):
+            desc.batchnorm[i] = 1 if b else 0
+        desc.bn_eps, desc.bn_momentum = float(bn_eps), float(bn_momentum)
         self.dropout = [float(p or 0.0) for p in (dropout if dropout is not None else [0.0] * L)]
         if len(self.dropout) != L:
             raise DcvError("one dropout probability per Linear layer expected")
@@ -367,6 +376,7 @@ class Mlp:
         self.rows_cap = 2 * self.max_batch if model == "deep_tica" else self.max_batch
         self.n_params = self.lib.dcv_mlp_num_params(self.h)
         self.offsets = [(self.lib.dcv_mlp_param_offset(self.h, l, 0), self.lib.dcv_mlp_param_offset(self.h, l, 1)) for l in range(L)]
+        self.bn_offsets = [(self.lib.dcv_mlp_param_offset(self.h, l, 2), self.lib.dcv_mlp_param_offset(self.h, l, 3)) for l in range(L)]
         self.log_width = self.lib.dcv_mlp_log_width(self.h)
         self.stats_len = self.lib.dcv_mlp_stats_len(self.h)
         self._log_cap = 0
@@ -387,9 +397,17 @@ class Mlp:
             pass
 
     # -- parameters
-    def set_linears(self, linears):
-        """linears: list of (weight[out,in], bias[out]) CPU float32 tensors / arrays."""
+    def set_linears(self, linears, bn=None):
+        """linears: list of (weight[out,in], bias[out]) CPU float32 tensors / arrays.  bn (optional): per Linear, None or a
+        dict(weight, bias, running_mean, running_var, num_batches_tracked) of the BatchNorm1d behind it; layers with a
+        normalisation and no entry start as a fresh BatchNorm1d (weight 1, bias 0, running mean 0 / variance 1)."""
         flat = np.zeros(self.n_params, dtype=np.float32)
+        for l in range(self.L):
+            if self.batchnorm[l]:
+                go, bo_ = self.bn_offsets[l]
+                d = (bn[l] if bn is not None else None) or {}
+                flat[go: go + self.dims[l + 1]] = np.asarray(d.get("weight", np.ones(self.dims[l + 1])), dtype=np.float32)
+                flat[bo_: bo_ + self.dims[l + 1]] = np.asarray(d.get("bias", np.zeros(self.dims[l + 1])), dtype=np.float32)
         for l, (w, b) in enumerate(linears):
             w = np.asarray(w, dtype=np.float32)
             b = np.asarray(b, dtype=np.float32)
@@ -399,6 +417,34 @@ class Mlp:
             flat[wo: wo + w.size] = w.ravel()
             flat[bo: bo + b.size] = b
         check(self.lib.dcv_mlp_set_params(self.h, flat.ctypes.data, _stream()), "dcv_mlp_set_params")
+        if bn is not None:
+            import ctypes as C
+
+            for l in range(self.L):
+                if self.batchnorm[l] and bn[l] is not None and "running_mean" in bn[l]:
+                    rm = np.ascontiguousarray(np.asarray(bn[l]["running_mean"], dtype=np.float32))
+                    rv = np.ascontiguousarray(np.asarray(bn[l]["running_var"], dtype=np.float32))
+                    nbt = C.c_int64(int(bn[l].get("num_batches_tracked", 0)))
+                    check(self.lib.dcv_mlp_bn_state(self.h, l, rm.ctypes.data, rv.ctypes.data, C.byref(nbt), 1, _stream()), "dcv_mlp_bn_state")
+
+    def get_bn(self):
+        """Per Linear: None, or the state of the BatchNorm1d behind it (weight, bias, running_mean, running_var, num_batches_tracked)."""
+        import ctypes as C
+
+        flat = np.empty(self.n_params, dtype=np.float32)
+        check(self.lib.dcv_mlp_get_params(self.h, flat.ctypes.data, _stream()), "dcv_mlp_get_params")
+        out = []
+        for l in range(self.L):
+            if not self.batchnorm[l]:
+                out.append(None)
+                continue
+            o = self.dims[l + 1]
+            go, bo_ = self.bn_offsets[l]
+            rm, rv, nbt = np.empty(o, np.float32), np.empty(o, np.float32), C.c_int64(0)
+            check(self.lib.dcv_mlp_bn_state(self.h, l, rm.ctypes.data, rv.ctypes.data, C.byref(nbt), 0, _stream()), "dcv_mlp_bn_state")
+            out.append({"weight": flat[go: go + o].copy(), "bias": flat[bo_: bo_ + o].copy(), "running_mean": rm, "running_var": rv,
+                        "num_batches_tracked": int(nbt.value)})
+        return out
 
     def get_linears(self):
         flat = np.empty(self.n_params, dtype=np.float32)

@@ -39,7 +39,7 @@ extern "C" {
 #define DCV_ESTATE (-4)  /* call order violated */
 #define DCV_ECALLBACK (-5) /* a host callback of the caller reported failure */
 
-#define DCV_ABI_VERSION 2
+#define DCV_ABI_VERSION 3
 
 int dcv_abi_version(void);
 const char* dcv_last_error(void);
@@ -84,7 +84,10 @@ int dcv_normalize(const float* X_d, float* Y_d, int64_t n, int32_t F, int64_t ld
  *   [ a = sum z_t | b = sum z_lag | A = sum z_t z_t^T | B = sum z_t z_lag^T ]   (raw sums).
  * All four blocks combine over shards by addition.  lag = 0 computes only a and A (PCA);
  * B and b are then zero.  FP32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulation over chunks
- * of <= 4096 rows, chunk partials summed in float64 in a fixed order (deterministic).
+ * of <= 2048 rows, chunk partials summed in float64 in a fixed order (deterministic).  With a shift the column sums a, b come
+ * from the kernel's own fragments, accumulated in float32 inside a chunk: shift_d must then be (close to) the column
+ * means -- what the calculators pass -- for those sums to keep float64-grade accuracy; without a shift a separate float64
+ * statistics pass forms them.
  * Algorithmic work: 4*n_pairs*F^2 flop (2*n*F^2 for lag 0), 4*n*F bytes. */
 size_t dcv_lagged_cov_workspace(int64_t n_pairs, int32_t F, int32_t lag);
 int dcv_lagged_cov(const float* X_d, int64_t n_pairs, int32_t F, int64_t ld, int32_t lag,
@@ -133,6 +136,13 @@ int dcv_project_linear(const float* X_d, int64_t n, int32_t F, int64_t ld,
 #define DCV_OPT_SGD 2      /* lr, momentum, dampening, nesterov, weight_decay */
 #define DCV_OPT_RMSPROP 3  /* lr, alpha, eps, weight_decay, momentum, centered */
 #define DCV_OPT_ADAGRAD 4  /* lr, lr_decay, eps, weight_decay, initial_accumulator_value */
+#define DCV_OPT_ADAMAX 5   /* lr, beta1, beta2, eps, weight_decay */
+#define DCV_OPT_NADAM 6    /* lr, beta1, beta2, eps, weight_decay, opt_p[0] = momentum_decay, opt_p[1] = decoupled_weight_decay */
+#define DCV_OPT_RADAM 7    /* lr, beta1, beta2, eps, weight_decay, opt_p[1] = decoupled_weight_decay */
+#define DCV_OPT_ADADELTA 8 /* lr, opt_p[0] = rho, eps, weight_decay */
+#define DCV_OPT_ASGD 9     /* lr, opt_p[0] = lambd, opt_p[1] = alpha, opt_p[2] = t0, weight_decay (the averaged copy `ax` is not a model
+                              parameter and is not kept) */
+#define DCV_OPT_RPROP 10   /* lr, opt_p[0..1] = etas (minus, plus), opt_p[2..3] = step_sizes (min, max) */
 
 #define DCV_MODEL_DEEPTICA 1 /* loss = -sum(eig^2) of the batch TICA of nn(x_t), nn(x_lag) */
 #define DCV_MODEL_AE 2       /* loss = mean(((dec(enc(xn)) - xn) * range)^2) */
@@ -156,10 +166,17 @@ typedef struct dcv_mlp_desc {
     double momentum, dampening;         /* SGD, RMSprop (momentum) */
     double alpha;                       /* RMSprop smoothing constant */
     double lr_decay, initial_accumulator_value; /* Adagrad */
+    double opt_p[4];                    /* further constants of the optimiser, see DCV_OPT_* */
     /* torch.nn.Dropout(p) behind the activation of each Linear (mlcolvar FeedForward order: Linear, activation,
      * dropout), active in training steps only; 0 = none.  Masks come from a counter-based generator keyed by `seed`. */
     float dropout[DCV_MAX_LAYERS];
     uint64_t seed;
+    /* torch.nn.BatchNorm1d(dims[l + 1]) behind Linear l (mlcolvar FeedForward order: Linear, activation, dropout, batchnorm);
+     * training steps normalise with the batch statistics (Deep-TICA: of each half of the batch separately, x_t first, as the
+     * reference's two forward calls do) and update the running statistics, evaluation steps and inference use the running
+     * ones.  weight / bias of the layer follow its Linear in the flat parameter buffer (dcv_mlp_param_offset which = 2, 3). */
+    int32_t batchnorm[DCV_MAX_LAYERS];
+    double bn_eps, bn_momentum;         /* torch defaults 1e-5, 0.1 */
 } dcv_mlp_desc;
 
 typedef struct dcv_mlp dcv_mlp; /* opaque; owns parameters, optimiser state and workspaces */
@@ -245,6 +262,11 @@ int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
 /* Rank of this engine in a data-parallel run: mixed into the key of the dropout counters, so that ranks holding the same
  * seed mask their local rows independently (default 0). */
 int dcv_mlp_set_rank(dcv_mlp* m, int32_t rank);
+/* Running statistics of the batch normalisation behind Linear `layer` (dcv_mlp_desc.batchnorm): set != 0 uploads
+ * running_mean / running_var (dims[layer + 1] floats each, host) and *num_batches_tracked, set == 0 downloads them.
+ * dcv_mlp_set_params resets them to a fresh BatchNorm1d (mean 0, variance 1, 0 batches). */
+int dcv_mlp_bn_state(dcv_mlp* m, int32_t layer, float* running_mean_h, float* running_var_h, int64_t* num_batches_tracked,
+                     int32_t set, void* stream);
 /* Test hook: post-activation output of Linear `layer` in the last forward (rows x dims[layer + 1] floats, dense). */
 int dcv_mlp_layer_output(dcv_mlp* m, int32_t layer, int64_t rows, float* out_d, void* stream);
 /* Convenience for one GPU: forward + backward(train=1) + apply. */

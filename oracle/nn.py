@@ -65,8 +65,11 @@ ACTIVATIONS = {
 }
 
 
-def feed_forward(layers: Sequence[int], activation: Sequence, dropout: Optional[Sequence] = None) -> torch.nn.Sequential:
-    """mlcolvar.core.nn.FeedForward body: Linear [, act][, Dropout] per layer (Appendix A.5).
+def feed_forward(layers: Sequence[int], activation: Sequence, dropout: Optional[Sequence] = None,
+                 batchnorm: Optional[Sequence] = None) -> torch.nn.Sequential:
+    """mlcolvar.core.nn.FeedForward body: Linear [, act][, Dropout][, BatchNorm1d] per layer (Appendix A.5; the order
+    activation -> dropout -> batchnorm is restated from knowledge of mlcolvar 1.2.2's feedforward.py -- parity unpinned:
+    no fixture of the reference carries a batch normalisation).
     ``activation`` / ``dropout`` have one entry per Linear (the reference appends the
     last-layer entry itself, cv_calculator.py:1155-1219).  Consumes the global torch RNG in
     construction order exactly as nn.Linear does."""
@@ -82,6 +85,8 @@ def feed_forward(layers: Sequence[int], activation: Sequence, dropout: Optional[
             mods.append(ACTIVATIONS[act]())
         if dropout[i] is not None:
             mods.append(MaskedDropout(p=dropout[i]))
+        if batchnorm is not None and batchnorm[i]:
+            mods.append(torch.nn.BatchNorm1d(layers[i + 1]))
     return torch.nn.Sequential(*mods)
 
 
@@ -129,10 +134,10 @@ def deeptica_loss(evals: torch.Tensor) -> torch.Tensor:
 class DeepTICAModel(torch.nn.Module):
     """norm_in -> nn -> tica (-> postprocessing); module tree of Appendix A.5."""
 
-    def __init__(self, layers, activation, dropout, norm_mean, norm_range, reg):
+    def __init__(self, layers, activation, dropout, norm_mean, norm_range, reg, batchnorm=None):
         super().__init__()
         self.norm_in = Normalization(norm_mean, norm_range) if norm_mean is not None else None
-        self.nn = feed_forward(layers, activation, dropout)
+        self.nn = feed_forward(layers, activation, dropout, batchnorm)
         d = layers[-1]
         self.reg = reg
         self.register_buffer("tica_evecs", torch.eye(d))
@@ -167,11 +172,11 @@ class AEModel(torch.nn.Module):
     """AutoEncoderCV: loss = mean((norm_in.inverse(decoder(encoder(norm_in(x)))) - x)^2)
     over batch x features (Appendix A.9)."""
 
-    def __init__(self, enc_layers, enc_act, enc_drop, dec_layers, dec_act, dec_drop, norm_mean, norm_range):
+    def __init__(self, enc_layers, enc_act, enc_drop, dec_layers, dec_act, dec_drop, norm_mean, norm_range, enc_bn=None, dec_bn=None):
         super().__init__()
         self.norm_in = Normalization(norm_mean, norm_range) if norm_mean is not None else None
-        self.encoder = feed_forward(enc_layers, enc_act, enc_drop)
-        self.decoder = feed_forward(dec_layers, dec_act, dec_drop)
+        self.encoder = feed_forward(enc_layers, enc_act, enc_drop, enc_bn)
+        self.decoder = feed_forward(dec_layers, dec_act, dec_drop, dec_bn)
         self.postprocessing: Optional[Normalization] = None
 
     def forward_cv(self, x):

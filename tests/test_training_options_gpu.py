@@ -165,6 +165,168 @@ def test_ae_dropout_step_matches_oracle_given_the_masks():
     eng.close()
 
 
+# ----------------------------------------------------------------------------- batch normalisation
+def _bn_modules(seq):
+    return [m for m in seq if isinstance(m, torch.nn.BatchNorm1d)]
+
+
+@pytest.mark.parametrize("kind", ["ae", "deep_tica"])
+def test_batchnorm_training_matches_torch(kind):
+    """`batchnorm` / `last_layer_batchnorm` of the YAML (cv_calculator.py:1155-1219, yaml_schemas/train_colvars.py:24-31):
+    torch.nn.BatchNorm1d behind a Linear (after activation and dropout).  Training mode: batch statistics -- for Deep-TICA of
+    the x_t call and of the x_lag call separately, x_t first -- and running-statistics updates; evaluation / inference: the
+    running statistics.  (i) the first step's gradients against a FLOAT64 run of the autograd oracle; (ii) eight SGD-with-momentum steps
+    against the float32 oracle: losses, every parameter incl. the normalisations' weight / bias, running mean / variance,
+    num_batches_tracked; (iii) an evaluation step and the inference path in eval mode."""
+    from deep_cartograph_amd import hip
+
+    F, lag, batch, d = 40, 3, 384, 2
+    Xn, m, r = normalized(ar_features(2600, F, 17))
+    torch.manual_seed(12)
+    if kind == "ae":
+        enc, dec = [F, 24, d], [d, 24, F]
+        acts = ["tanh", None, "leaky_relu", None]
+        bnf = [True, False, True, True]            # incl. the decoder's output layer (last_layer_batchnorm)
+        ref = onn.AEModel(enc, acts[:2], None, dec, acts[2:], None, None, None, enc_bn=bnf[:2], dec_bn=bnf[2:])
+        dims, seqs, latent = enc + dec[1:], [ref.encoder, ref.decoder], 2
+        eng = hip.Mlp("ae", dims, acts, max_batch=batch, latent_layer=latent, optimizer="SGD", lr=0.05, momentum=0.5, batchnorm=bnf)
+        eng.set_feature_range(np.ones(F, np.float32))
+    else:
+        # (no normalisation behind the LAST Deep-TICA layer here: the loss is invariant under any invertible linear map of the
+        # outputs, so that layer's weight and bias would have exactly zero gradients and Adam would move them by rounding noise)
+        dims, acts, bnf = [F, 24, 12, d], ["leaky_relu", "tanh", None], [True, True, False]
+        ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6, batchnorm=bnf)
+        seqs = [ref.nn]
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6, optimizer="SGD", lr=0.05, momentum=0.5, batchnorm=bnf)
+    lins = [m_ for q in seqs for m_ in linears_of(q)]
+    bns = [m_ for q in seqs for m_ in _bn_modules(q)]
+    with torch.no_grad():   # not the trivial weight 1 / bias 0
+        for b in bns:
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.uniform_(-0.3, 0.3)
+    bn_state = []
+    it = iter(bns)
+    for flag in bnf:
+        if flag:
+            b = next(it)
+            bn_state.append({"weight": b.weight.detach().numpy(), "bias": b.bias.detach().numpy(), "running_mean": b.running_mean.numpy(),
+                             "running_var": b.running_var.numpy(), "num_batches_tracked": 0})
+        else:
+            bn_state.append(None)
+    eng.set_linears([(l.weight.detach().numpy(), l.bias.detach().numpy()) for l in lins], bn=bn_state)
+    Xd = torch.from_numpy(Xn).cuda()
+    xt = torch.from_numpy(Xn)
+
+    def ref_step(model, x, r0):
+        if kind == "ae":
+            return model.step(x[r0:r0 + batch])[0]
+        return model.step(x[r0:r0 + batch], x[r0 + lag:r0 + lag + batch])[0]
+
+    # (i) first step, float64
+    ref64 = copy.deepcopy(ref).double().train()
+    eng.reset_log(32)
+    eng.forward(Xd, row0=5, batch=batch, train=True)
+    eng.backward(Xd, row0=5, batch=batch)
+    loss64 = ref_step(ref64, xt.double(), 5)
+    loss64.backward()
+    assert abs(eng.read_log()[0, 0] - float(loss64)) < 2e-5 * max(1.0, abs(float(loss64)))
+    g = eng.grads_view().cpu().numpy()
+    lins64 = [m_ for q in ([ref64.encoder, ref64.decoder] if kind == "ae" else [ref64.nn]) for m_ in linears_of(q)]
+    bns64 = [m_ for q in ([ref64.encoder, ref64.decoder] if kind == "ae" else [ref64.nn]) for m_ in _bn_modules(q)]
+    worst = 0.0
+    gscale = max(float(np.max(np.abs(lin.weight.grad.numpy()))) for lin in lins64)
+
+    def cmp(got, exp):
+        """relative deviation -- or, where the float64 gradient is exactly zero by an invariance of the loss (a constant shift
+        in front of a normalisation or of Deep-TICA's mean removal: its bias, or the bias of a normalisation feeding such a
+        Linear), the size of the engine's rounding noise against the largest gradient of the step"""
+        nonlocal worst
+        if np.max(np.abs(exp)) < 1e-12:
+            assert np.max(np.abs(got)) < 1e-6 * gscale, (np.max(np.abs(got)), gscale)
+            return
+        worst = max(worst, rel_err(got, exp))
+
+    for l, lin in enumerate(lins64):
+        wo, bo = eng.offsets[l]
+        gw, gb = lin.weight.grad.numpy(), lin.bias.grad.numpy()
+        cmp(g[wo:wo + gw.size].reshape(gw.shape), gw)
+        cmp(g[bo:bo + gb.size], gb)
+    it64 = iter(bns64)
+    for l, flag in enumerate(bnf):
+        if flag:
+            b = next(it64)
+            go, bo_ = eng.bn_offsets[l]
+            cmp(g[go:go + b.weight.numel()], b.weight.grad.numpy())
+            cmp(g[bo_:bo_ + b.bias.numel()], b.bias.grad.numpy())
+    print(f"{kind} batchnorm step: worst gradient deviation from float64 = {worst:.2e}")
+    assert worst < 5e-5
+    # (ii) training steps, float32 oracle (fresh engine state: the forward above already updated the running statistics)
+    eng.set_linears([(l.weight.detach().numpy(), l.bias.detach().numpy()) for l in lins], bn=bn_state)
+    # SGD with momentum: the update is linear in the gradient.  (Adam divides by |g|: parameters whose exact gradient is zero
+    # by an invariance -- see cmp above -- take +-lr steps of rounding noise in ANY float32 implementation, DESIGN.md section 2.)
+    opt = torch.optim.SGD(ref.parameters(), lr=0.05, momentum=0.5)
+    ref.train()
+    eng.reset_log(32)
+    ref_losses = []
+    for i in range(8):
+        r0 = (i * 131) % (Xn.shape[0] - batch - lag)
+        eng.train_step(Xd, row0=r0, batch=batch)
+        opt.zero_grad()
+        loss = ref_step(ref, xt, r0)
+        loss.backward()
+        opt.step()
+        ref_losses.append(float(loss))
+    np.testing.assert_allclose(eng.read_log()[:, 0], ref_losses, rtol=2e-4, atol=2e-5)
+    for (w, b), lin in zip(eng.get_linears(), lins):
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=5e-5)
+    got_bn = [b for b in eng.get_bn() if b is not None]
+    for gb_, b in zip(got_bn, bns):
+        np.testing.assert_allclose(gb_["weight"], b.weight.detach().numpy(), atol=5e-5)
+        np.testing.assert_allclose(gb_["running_mean"], b.running_mean.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(gb_["running_var"], b.running_var.numpy(), rtol=1e-4, atol=1e-6)
+        assert gb_["num_batches_tracked"] == int(b.num_batches_tracked) == (8 if kind == "ae" else 16)
+    # (iii) evaluation mode
+    ref.eval()
+    eng.reset_log(4)
+    eng.eval_step(Xd, row0=700, batch=batch)
+    with torch.no_grad():
+        le = float(ref_step(ref, xt, 700))
+        exp = (ref.forward_cv(xt[:600]) if kind == "ae" else ref.forward_nn(xt[:600])).numpy()
+    assert abs(eng.read_log()[0, 0] - le) < 2e-4 * max(1.0, abs(le))
+    out, _ = eng.infer(Xd[:600])
+    np.testing.assert_allclose(out.cpu().numpy(), exp, atol=5e-5)
+    assert [b["num_batches_tracked"] for b in eng.get_bn() if b is not None] == [int(b.num_batches_tracked) for b in bns]   # eval steps track nothing
+    eng.close()
+
+
+def test_batchnorm_calculator_and_export(features, tmp_path):
+    """A Deep-TICA calculator with batchnorm [True, False] + last_layer_batchnorm: the fit runs, the exported TorchScript
+    carries the BatchNorm1d modules (names of the reference's module tree) and, loaded with plain torch.jit, reproduces
+    the calculator's projection; a model.zip round trip through CVCalculator.load projects identically."""
+    import io
+    import zipfile
+
+    from deep_cartograph_amd.cv_calculator import CVCalculator
+
+    X, names = features
+    arch = json.loads(json.dumps(TEST_COMMON["architecture"]))
+    arch["encoder"]["batchnorm"] = [True, False]
+    arch["encoder"]["last_layer_batchnorm"] = True
+    calc = make_calc("deep_tica", tmp_path, architecture=arch)
+    calc.set_training_matrix(X.copy(), names)
+    df = calc.run(2)
+    assert df is not None and df.shape == (164, 2)
+    with zipfile.ZipFile(tmp_path / "deep_tica" / "model.zip") as z:
+        ts = torch.jit.load(io.BytesIO(z.read("model/cv_weights.pt")))
+    bnames = sorted(n for n, _ in ts.named_buffers())
+    assert sum(n.endswith("running_mean") for n in bnames) == 2 and sum(n.endswith("num_batches_tracked") for n in bnames) == 2, bnames
+    assert all(n.startswith("nn.nn.") for n in bnames if "running" in n)   # inside the FeedForward's Sequential, as the reference's tree
+    with torch.no_grad():
+        np.testing.assert_allclose(ts(torch.from_numpy(X)).numpy(), df.to_numpy(), atol=5e-5)
+    loaded = CVCalculator.load(str(tmp_path / "deep_tica" / "model.zip"), str(tmp_path / "reload"))
+    np.testing.assert_allclose(loaded.project_data(torch.from_numpy(X.copy())).numpy(), df.to_numpy(), atol=5e-5)
+
+
 # ----------------------------------------------------------------------------- optimisers
 @pytest.mark.parametrize("name,kwargs", [
     ("Adam", dict(lr=2e-3, weight_decay=1e-3)),
@@ -176,6 +338,14 @@ def test_ae_dropout_step_matches_oracle_given_the_masks():
     ("RMSprop", dict(lr=1e-3, momentum=0.5, centered=True)),
     ("RMSprop", dict(lr=2e-3, alpha=0.9, weight_decay=1e-3)),
     ("Adagrad", dict(lr=0.02, lr_decay=0.01, initial_accumulator_value=0.1)),
+    ("Adamax", dict(lr=2e-3, weight_decay=1e-3)),
+    ("NAdam", dict(lr=2e-3, momentum_decay=4e-3)),
+    ("NAdam", dict(lr=1e-3, weight_decay=0.01, decoupled_weight_decay=True)),
+    ("RAdam", dict(lr=2e-3)),                       # 12 steps: rho_t crosses 5 at step 6 -- both branches run
+    ("RAdam", dict(lr=1e-3, weight_decay=0.01, decoupled_weight_decay=True, betas=(0.9, 0.9))),
+    ("Adadelta", dict(lr=1.0, rho=0.9, weight_decay=1e-4)),
+    ("ASGD", dict(lr=0.02, lambd=1e-3, alpha=0.75)),
+    ("Rprop", dict(lr=1e-3, etas=(0.5, 1.2), step_sizes=(1e-6, 1e-2))),
 ])
 def test_optimizers_follow_torch(name, kwargs):
     """optimizer.name / kwargs of the YAML (cv_calculator.py:1377-1380 -> getattr(torch.optim, name)): 12 AE steps on the
@@ -190,7 +360,10 @@ def test_optimizers_follow_torch(name, kwargs):
     torch.manual_seed(31)
     ref = onn.AEModel(enc, acts[:2], None, dec, acts[2:], None, m, r)
     lins = linears_of(ref.encoder) + linears_of(ref.decoder)
-    ek = dict(kwargs)
+    from deep_cartograph_amd.cv_calculator import NonLinear, _OPTIMIZERS
+
+    ek = NonLinear._engine_optimizer_kwargs(name, {**_OPTIMIZERS[name], **kwargs})   # the calculators' own mapping onto the engine
+    ek.pop("optimizer")
     eng = hip.Mlp("ae", enc + dec[1:], acts, max_batch=batch, latent_layer=2, optimizer=name, **ek)
     push_params(eng, lins)
     eng.set_feature_range(r)

@@ -55,6 +55,10 @@ def parse():
     p.add_argument("--other-mode-steps", type=int, default=200)
     p.add_argument("--backend", default="nccl", help="torch.distributed backend of a multi-rank run: 'nccl' (= RCCL over xGMI; default) or "
                                                     "'gloo' (rehearsals of the N > 1 control flow with several ranks on one GPU)")
+    p.add_argument("--native-rccl", action="store_true",
+                   help="data-parallel steps through the library's own RCCL communicator (dcv_comm_*: forward, all-reduces, backward and "
+                        "update inside one C call) instead of torch.distributed's; torch.distributed still provides the launcher's "
+                        "rendezvous, the barriers and the unique-id broadcast")
     p.add_argument("--config", choices=["c4", "c2"], default="c4",
                    help="c4 (default): the headline, Deep-TICA on 10M x 512; c2: BASELINE.json configs[1], autoencoder 128-64-32-2-32-64-128 on "
                         "1M x 128 at batch 4096 (its own metric line with roofline and cpu_baseline; one GPU)")
@@ -108,8 +112,9 @@ class Fit:
 
     PRIME = 30   # untimed priming steps in front of the W warm-up steps of every run()
 
-    def __init__(self, hip, dist, Xn, dims, acts, lag, global_batch, world, lr, linears, n_local):
+    def __init__(self, hip, dist, Xn, dims, acts, lag, global_batch, world, lr, linears, n_local, step_comm=None):
         self.hip, self.dist, self.Xn, self.dims, self.lag = hip, dist, Xn, dims, lag
+        self.step_comm = step_comm if step_comm is not None else dist   # what the data-parallel steps exchange through
         self.gb = global_batch
         self.lb = global_batch // world
         P_local = n_local - lag
@@ -126,7 +131,7 @@ class Fit:
         if self.dist is None:
             eng.train_step(self.Xn, row0=r0, batch=self.lb)
         else:   # statistics all-reduce, then the gradient all-reduce of the upper layers under the layer-0 weight gradient
-            eng.data_parallel_step(self.Xn, self.dist, self.gb, row0=r0, batch=self.lb, train=True)
+            eng.data_parallel_step(self.Xn, self.step_comm, self.gb, row0=r0, batch=self.lb, train=True)
 
     def validation_pass(self):
         eng = self.eng
@@ -135,7 +140,7 @@ class Fit:
             if self.dist is None:
                 eng.eval_step(self.Xn, row0=r0, batch=self.lb)
             else:
-                eng.data_parallel_step(self.Xn, self.dist, self.gb, row0=r0, batch=self.lb, train=False)
+                eng.data_parallel_step(self.Xn, self.step_comm, self.gb, row0=r0, batch=self.lb, train=False)
 
     def barrier(self):
         if self.dist is not None:
@@ -398,7 +403,8 @@ def main():
     traffic_tables = load_traffic_tables()
 
     # ---- headline: the contract batch
-    fit = Fit(hip, dist, Xn, dims, acts, lag, a.batch, world, a.lr, linears, n_local)
+    step_comm = hip.RcclComm(dist, device=dev) if (dist is not None and a.native_rccl) else None
+    fit = Fit(hip, dist, Xn, dims, acts, lag, a.batch, world, a.lr, linears, n_local, step_comm)
     elapsed, prof, log = fit.run(a.steps, a.warmup, a.profile_every)
     val_timed = fit.val_timed
     head_roof = fit.roofline(prof, a.gemm_mode, traffic_tables) if rank == 0 else None
@@ -423,7 +429,7 @@ def main():
     # ---- the same fit at a large global batch (MFMA-bound instead of launch / latency-bound)
     large = None
     if a.large_batch > 0 and a.large_batch % world == 0 and a.large_batch != a.batch and (n_local - lag) * 0.8 >= a.large_batch // world:
-        fl_ = Fit(hip, dist, Xn, dims, acts, lag, a.large_batch, world, a.lr, linears, n_local)
+        fl_ = Fit(hip, dist, Xn, dims, acts, lag, a.large_batch, world, a.lr, linears, n_local, step_comm)
         el, prof_l, _ = fl_.run(a.large_steps, 5, 1)
         if rank == 0:
             large = {"global_batch": a.large_batch, "value": a.large_steps * a.large_batch / el, "unit": "frames/s",
@@ -458,6 +464,8 @@ def main():
                             f"validation pass at each epoch end the {a.steps} timed steps cross ({val_timed} validation steps inside the timed "
                             f"region of this run); contiguous batches evaluate the batch + lag rows shared by x_t and x_lag once",
                 "frames": a.frames, "features": F, "global_batch": a.batch, "parallelism": f"frame-shard dp{world}",
+                "collectives": (None if dist is None else ("libdcv RCCL communicator (dcv_comm_*)" if step_comm is not None else
+                                                           f"torch.distributed {a.backend} through the all-reduce callback of dcv_mlp_dp_step")),
                 "steps_per_epoch": steps_per_epoch, "val_steps_per_epoch": val_steps, "validation_steps_timed": val_timed, "params": sw,
                 "gemm_mode": a.gemm_mode,
             },

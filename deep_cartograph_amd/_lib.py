@@ -90,6 +90,14 @@ SIGNATURES = {
     "dcv_mlp_apply": (C.c_int, [_P, _P]),
     "dcv_mlp_set_upper_grads_callback": (C.c_int, [_P, _P, _P]),
     "dcv_mlp_dp_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I64, _I32, _I32, _P, _P, _P]),
+    "dcv_comm_unique_id": (C.c_int, [_P]),
+    "dcv_comm_create": (C.c_int, [_I32, _I32, _P, C.POINTER(_P)]),
+    "dcv_comm_destroy": (None, [_P]),
+    "dcv_comm_bind_stream": (C.c_int, [_P, _P]),
+    "dcv_comm_allreduce": (C.c_int, [_P, _P, _I64, _I32, _I32, _P]),
+    "dcv_comm_dp_allreduce_fn": (_P, []),
+    "dcv_comm_world": (_I32, [_P]),
+    "dcv_comm_rank": (_I32, [_P]),
     "dcv_mlp_set_rank": (C.c_int, [_P, _I32]),
     "dcv_mlp_bn_state": (C.c_int, [_P, _I32, _P, _P, C.POINTER(_I64), _I32, _P]),
     "dcv_mlp_layer_output": (C.c_int, [_P, _I32, _I64, _P, _P]),

@@ -306,6 +306,46 @@ def nearest_point(train: torch.Tensor, sup: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------- MLP engine
+class RcclComm:
+    """RCCL communicator owned by the library (dcv_comm_*): the collectives of a data-parallel step are then issued by
+    libdcv.so itself, in stream order with its kernels.  `dist` (an initialised torch.distributed, any backend) is used
+    once, to hand rank 0's 128-byte unique id to the other ranks; world = 1 needs no bootstrap at all."""
+
+    def __init__(self, dist=None, device="cuda"):
+        import ctypes as C
+
+        self.lib = _lib.load()
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            check(self.lib.dcv_comm_unique_id(uid), "dcv_comm_unique_id")
+        if world > 1:
+            backend = dist.get_backend()
+            t = torch.tensor(list(uid), dtype=torch.uint8, device=device if backend == "nccl" else "cpu")
+            dist.broadcast(t, src=0)
+            uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+        h = C.c_void_p()
+        check(self.lib.dcv_comm_create(world, rank, uid, C.byref(h)), "dcv_comm_create")
+        self.h, self.world, self.rank = h, world, rank
+
+    def all_reduce(self, t: torch.Tensor, op: str = "sum"):
+        _require_gpu(t)
+        dt = {torch.float32: 0, torch.float64: 1}[t.dtype]
+        check(self.lib.dcv_comm_allreduce(self.h, _ptr(t), t.numel(), dt, {"sum": 0, "min": 1, "max": 2}[op], _stream()), "dcv_comm_allreduce")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dcv_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Mlp:
     """Owner of a ``dcv_mlp`` handle (Deep-TICA or autoencoder chain of Linear layers).
 
@@ -561,6 +601,13 @@ class Mlp:
         import ctypes as C
 
         rows = int(batch if batch is not None else idx.numel())
+        if isinstance(dist, RcclComm):   # the library's own communicator: nothing of the step runs in Python
+            env = os.environ.get("DCV_DP_OVERLAP")
+            overlap = (rows >= 32768) if env is None else env == "1"
+            check(self.lib.dcv_comm_bind_stream(dist.h, _stream()), "dcv_comm_bind_stream")
+            check(self.lib.dcv_mlp_dp_step(self.h, *self._args(Xn, idx, row0, rows), int(global_batch), 1 if train else 0, 1 if overlap else 0,
+                                           self.lib.dcv_comm_dp_allreduce_fn(), dist.h, _stream()), "dcv_mlp_dp_step")
+            return
         env = os.environ.get("DCV_DP_OVERLAP")
         # The two-piece form pays one more collective launch (~15-20 us of latency at these message sizes) to hide the
         # upper layers' all-reduce under the layer-0 weight gradient: worth it only when that product outlasts a

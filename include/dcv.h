@@ -259,6 +259,23 @@ int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void* user), void* u
 typedef int (*dcv_allreduce_fn)(void* user, void* buf_d, int64_t count, int32_t dtype, int32_t phase);
 int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                     int64_t global_batch, int32_t train, int32_t overlap, dcv_allreduce_fn fn, void* user, void* stream);
+/* ---- RCCL communicator (one process per GPU; RCCL over xGMI inside a node).  The collectives of a frame-sharded fit issued
+ * by the library itself, in stream order with its kernels.  dcv_comm_unique_id: rank 0 creates the 128-byte id and the
+ * caller's bootstrap hands it to every rank; dcv_comm_create: collective over all ranks (ncclCommInitRank on the current
+ * device).  dcv_comm_allreduce: in place, op 0 = SUM, 1 = MIN, 2 = MAX, dtype DCV_DTYPE_*, enqueued on `stream`.
+ * dcv_comm_dp_allreduce_fn() is an all-reduce callback for dcv_mlp_dp_step with user = the communicator, after
+ * dcv_comm_bind_stream(comm, stream) with the step's launch stream: the whole data-parallel step then runs inside the
+ * library (the DCV_DP_UPPER_START exchange on a side stream, joined at DCV_DP_WAIT).  librccl.so is opened at run time.
+ * Replaces what a torch.distributed / lightning DDP wrapper would do around cv_calculator.py:1515-1524. */
+typedef struct dcv_comm dcv_comm;
+int dcv_comm_unique_id(void* id_out_128);
+int dcv_comm_create(int32_t world, int32_t rank, const void* id_128, dcv_comm** out);
+void dcv_comm_destroy(dcv_comm* c);
+int dcv_comm_bind_stream(dcv_comm* c, void* stream);
+int dcv_comm_allreduce(dcv_comm* c, void* buf_d, int64_t count, int32_t dtype, int32_t op, void* stream);
+dcv_allreduce_fn dcv_comm_dp_allreduce_fn(void);
+int32_t dcv_comm_world(const dcv_comm* c);
+int32_t dcv_comm_rank(const dcv_comm* c);
 /* Rank of this engine in a data-parallel run: mixed into the key of the dropout counters, so that ranks holding the same
  * seed mask their local rows independently (default 0). */
 int dcv_mlp_set_rank(dcv_mlp* m, int32_t rank);

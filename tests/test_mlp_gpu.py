@@ -576,3 +576,50 @@ def test_graphed_steps_match_plain_launches():
         np.testing.assert_array_equal(w0, w1)
         np.testing.assert_array_equal(b0, b1)
     np.testing.assert_array_equal(plain_log, graphed_log)
+
+
+def test_native_rccl_communicator_world1():
+    """dcv_comm_* (the library's own RCCL communicator) with one rank: creation from a unique id, an in-place all-reduce,
+    and data-parallel steps through dcv_mlp_dp_step + dcv_comm_dp_allreduce_fn -- entirely inside the library -- against
+    the same steps through the torch.distributed-free single-GPU path.  (No multi-GPU node is available to the builder:
+    a multi-rank communicator has not executed; bench.py --native-rccl is the switch for a node that has one.)"""
+    from deep_cartograph_amd import hip
+
+    comm = hip.RcclComm(None)
+    assert comm.world == 1 and comm.rank == 0
+    t = torch.arange(1000, dtype=torch.float64, device="cuda")
+    comm.all_reduce(t)
+    torch.cuda.synchronize()
+    assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float64))
+    dims, lag, batch = [64, 32, 16, 3], 5, 1024
+    acts = ["leaky_relu", "tanh", None]
+    Xn, _, _ = normalized(ar_features(4000, dims[0], 3))
+    torch.manual_seed(9)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    Xd = torch.from_numpy(Xn).cuda()
+    res = {}
+    for mode in ("native", "single", "native_overlap"):
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6, lr=1e-3)
+        push_params(eng, linears_of(ref.nn))
+        eng.reset_log(16)
+        if mode == "native_overlap":
+            os_env = __import__("os").environ
+            os_env["DCV_DP_OVERLAP"] = "1"
+        for i in range(5):
+            if mode == "single":
+                eng.train_step(Xd, row0=17 * i, batch=batch)
+            else:
+                eng.data_parallel_step(Xd, comm, batch, row0=17 * i, batch=batch, train=True)
+        if mode != "single":
+            eng.data_parallel_step(Xd, comm, batch, row0=2000, batch=batch, train=False)
+        else:
+            eng.eval_step(Xd, row0=2000, batch=batch)
+        if mode == "native_overlap":
+            os_env.pop("DCV_DP_OVERLAP", None)
+        res[mode] = (eng.read_log()[:, 0].copy(), [w for w, _ in eng.get_linears()])
+        eng.close()
+    for mode in ("native", "native_overlap"):
+        np.testing.assert_allclose(res[mode][0], res["single"][0], rtol=1e-5, atol=1e-6)
+        for w, w0 in zip(res[mode][1], res["single"][1]):
+            np.testing.assert_allclose(w, w0, atol=2e-6)
+    comm.close()

@@ -473,17 +473,20 @@ def test_separate_validation_set(features, tmp_path):
 
 
 def test_unsupported_options_skip_the_cv_like_a_failed_fit(features, tmp_path):
-    """batchnorm and optimisers outside the engine's set are refused explicitly: the try is logged as failed and run()
-    returns None -- what the reference does with any exception inside a try (cv_calculator.py:1541-1542, :407-409)."""
+    """The two torch.optim classes the engine does not run (LBFGS: closure-driven; SparseAdam: rejects dense gradients inside
+    torch itself) are refused explicitly: the try is logged as failed and run() returns None -- what the reference does
+    with any exception inside a try (cv_calculator.py:1541-1542, :407-409).  Every other optimiser name and batch
+    normalisation run (test_optimizers_follow_torch, test_batchnorm_*)."""
     X, names = features
-    arch = json.loads(json.dumps(TEST_COMMON["architecture"]))
-    arch["encoder"]["batchnorm"] = [True, False]
-    calc = make_calc("deep_tica", tmp_path / "bn", architecture=arch, training=_training(max_epochs=2))
-    calc.set_training_matrix(X.copy(), names)
-    assert calc.run(2) is None
+    for name in ("LBFGS", "SparseAdam"):
+        tr = _training(max_epochs=2)
+        tr["optimizer"] = {"name": name, "kwargs": {"lr": 1e-3}}
+        calc = make_calc("ae", tmp_path / name, training=tr)
+        calc.set_training_matrix(X.copy(), names)
+        assert calc.run(2) is None
     tr = _training(max_epochs=2)
-    tr["optimizer"] = {"name": "LBFGS", "kwargs": {"lr": 1e-3}}
-    calc = make_calc("ae", tmp_path / "opt", training=tr)
+    tr["optimizer"] = {"name": "NoSuchOptimizer", "kwargs": {}}
+    calc = make_calc("ae", tmp_path / "unknown", training=tr)
     calc.set_training_matrix(X.copy(), names)
     assert calc.run(2) is None
 

@@ -137,9 +137,14 @@ struct GemmDims {
 // one being multiplied); the register-staged loop always double-buffers in the first two.
 // SPLIT: FP32-accurate products on the BF16 matrix pipe (see split3 / mfma16 below) instead of the
 // FP32-input MFMA.
-// PL (SPLIT, NT products only): bit 0 / bit 1 = the A / B operand arrives pre-split into its three bf16 planes
+// PL (SPLIT): bit 0 / bit 1 (NT products only) = the A / B operand arrives pre-split into its three bf16 planes
 // (Operand::planes), so its share of the in-register split -- the vector-ALU work that bounds the SPLIT flavour --
-// disappears from the main loop.
+// disappears from the main loop.  bit 2 / bit 3 = the A / B operand (contraction-contiguous kinds) is an ordinary fp32
+// matrix, staged through registers and split ONCE PER WORKGROUP when the stage is stored to LDS, as three plane images:
+// the in-register split after the fragment read is repeated by every wave that shares a fragment (two of the four waves
+// of a 2 x 2 layout), so this halves the vector-ALU work without the 1.5 x global traffic of pre-split operands --
+// what bounds the small-batch products (measured at 8192 x 256 x 512: in-register split 21.9 us, vector-ALU-bound;
+// pre-split planes 22.5 us, bound by the L2 -> LDS traffic; without loads 20.7 vs 14.3 us).
 template <int WAVES_M_, int WAVES_N_, int FM_, int FN_, int KB_, int NBUF_ = 2, bool SPLIT_ = false, int PL_ = 0>
 struct TileCfg {
     static constexpr int WAVES_M = WAVES_M_, WAVES_N = WAVES_N_, FM = FM_, FN = FN_, KB = KB_, NBUF = NBUF_;
@@ -147,8 +152,8 @@ struct TileCfg {
     static constexpr int PL = PL_;
     static_assert(PL == 0 || SPLIT, "plane operands belong to the split flavour");
     // LDS floats of one stage: an fp32 tile is [T][KB] floats, a plane tile three [T][KB/2] images
-    static constexpr int A_SZ = (PL & 1) ? 3 * (WAVES_M_ * FM_ * 32) * (KB_ / 2) : (WAVES_M_ * FM_ * 32) * KB_;
-    static constexpr int B_SZ = (PL & 2) ? 3 * (WAVES_N_ * FN_ * 32) * (KB_ / 2) : (WAVES_N_ * FN_ * 32) * KB_;
+    static constexpr int A_SZ = (PL & 5) ? 3 * (WAVES_M_ * FM_ * 32) * (KB_ / 2) : (WAVES_M_ * FM_ * 32) * KB_;
+    static constexpr int B_SZ = (PL & 10) ? 3 * (WAVES_N_ * FN_ * 32) * (KB_ / 2) : (WAVES_N_ * FN_ * 32) * KB_;
     static_assert(NBUF >= 2 && NBUF <= 8, "NBUF");
     static constexpr int TM = WAVES_M * FM * 32;
     static constexpr int TN = WAVES_N * FN * 32;
@@ -315,6 +320,38 @@ struct MMajorStage {
 #pragma unroll
         for (int i = 0; i < PER; ++i)
             if (UNITS % 256 == 0 || t + 256 * i < UNITS) *reinterpret_cast<float4*>(lds + (t + 256 * i) * 4) = r[i];
+    }
+    // The staged fp32 values split into their three bf16 pieces on the way to LDS (TileCfg::PL bits 2 / 3): plane q of the
+    // tile is an MMAJOR image [T][KB / 2] floats (= [T][KB] bf16) at lds + q * T * KB / 2, its 16-byte chunks (8
+    // consecutive k) swizzled exactly as the pre-split operands' images are, so read_frags8 reads either alike.  A
+    // thread's 4 floats are one half of such a chunk: 8 bytes per plane.
+    __device__ __forceinline__ void store_planes(float* lds, int t) const {
+        constexpr int KF = KB / 2, CPRP = KF / 4, RPBRP = 64 / KF;
+        const int c4 = kofs >> 2;   // this thread's logical 4-float chunk of its rows (the same in every unit)
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int u = t + 256 * i;
+            if (UNITS % 256 == 0 || u < UNITS) {
+                const int row = u / CPR;
+                const int off = row * KF + (((c4 >> 1) ^ ((row / RPBRP) % CPRP)) << 2) + (c4 & 1) * 2;
+                const unsigned a = __float_as_uint(r[i].x), b = __float_as_uint(r[i].y), c = __float_as_uint(r[i].z), d = __float_as_uint(r[i].w);
+                uint2 p1, p2, p3;
+                p1.x = __builtin_amdgcn_perm(b, a, 0x07060302);
+                p1.y = __builtin_amdgcn_perm(d, c, 0x07060302);
+                const float ra = r[i].x - __uint_as_float(a & 0xFFFF0000u), rb = r[i].y - __uint_as_float(b & 0xFFFF0000u);
+                const float rc = r[i].z - __uint_as_float(c & 0xFFFF0000u), rd = r[i].w - __uint_as_float(d & 0xFFFF0000u);
+                const unsigned a2 = __float_as_uint(ra), b2 = __float_as_uint(rb), c2 = __float_as_uint(rc), d2 = __float_as_uint(rd);
+                p2.x = __builtin_amdgcn_perm(b2, a2, 0x07060302);
+                p2.y = __builtin_amdgcn_perm(d2, c2, 0x07060302);
+                const float sa = ra - __uint_as_float(a2 & 0xFFFF0000u), sb = rb - __uint_as_float(b2 & 0xFFFF0000u);
+                const float sc = rc - __uint_as_float(c2 & 0xFFFF0000u), sd = rd - __uint_as_float(d2 & 0xFFFF0000u);
+                p3.x = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302);
+                p3.y = __builtin_amdgcn_perm(__float_as_uint(sd), __float_as_uint(sc), 0x07060302);
+                *reinterpret_cast<uint2*>(lds + off) = p1;
+                *reinterpret_cast<uint2*>(lds + T * KF + off) = p2;
+                *reinterpret_cast<uint2*>(lds + 2 * T * KF + off) = p3;
+            }
+        }
     }
 };
 
@@ -526,11 +563,16 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // have produced from the fp32 value.  Such kernels have no register-staged loop: the launch guarantees K % KB == 0
     // and 16-byte loads, and ragged row tiles read clamped rows (MMajorStage::init<true>).
     constexpr int PL = Cfg::PL;
-    constexpr bool PA = (PL & 1) != 0, PB = (PL & 2) != 0;
-    static_assert(PL == 0 || (MODE == kNT && NB == 1 && VEC && Cfg::SPLIT), "plane operands: NT products of the split flavour");
+    constexpr bool PRE = (PL & 3) != 0;                      // an operand arrives pre-split (pure LDS-DMA kernel)
+    constexpr bool PSA = (PL & 4) != 0, PSB = (PL & 8) != 0;  // fp32 operand split when its stage is stored to LDS (register-staged kernel)
+    constexpr bool PA = (PL & 5) != 0, PB = (PL & 10) != 0;   // the operand's LDS image is three plane images
+    static_assert(!PRE || (MODE == kNT && NB == 1 && VEC && Cfg::SPLIT), "plane operands: NT products of the split flavour");
+    static_assert(!(PSA || PSB) || (!PRE && NB == 1 && Cfg::SPLIT), "split-at-store: split flavour, one B operand, no pre-split operand beside it");
+    static_assert(!PSA || MODE == kNT || MODE == kNN, "split-at-store of A needs a contraction-contiguous A");
+    static_assert(!PSB || MODE == kNT, "split-at-store of B needs a contraction-contiguous B");
     constexpr int KF = KB / 2;           // floats per row of a plane image
-    constexpr int KA = PA ? KF : KB, KBB = PB ? KF : KB;
-    constexpr int NPA = PA ? 3 : 1, NPB = PB ? 3 : 1;
+    constexpr int KA = (PL & 1) ? KF : KB, KBB = (PL & 2) ? KF : KB;   // row length of the stage objects' GLOBAL side
+    constexpr int NPA = (PL & 1) ? 3 : 1, NPB = (PL & 2) ? 3 : 1;
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = t >> 6;
@@ -557,9 +599,9 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     KMajorStage<TM, KB, VEC, GATHER> ak;
     MMajorStage<TN, KBB, VEC, GATHER> bm;
     KMajorStage<TN, KB, VEC, GATHER> bk[NB];
-    if constexpr (A_MM) am.template init<PL != 0>(A, m0, d.M, t);
+    if constexpr (A_MM) am.template init<PRE>(A, m0, d.M, t);
     else ak.init(A, m0, d.M, t);
-    if constexpr (B_MM) bm.template init<PL != 0>(B, n0, d.N, t);
+    if constexpr (B_MM) bm.template init<PRE>(B, n0, d.N, t);
     else {
 #pragma unroll
         for (int b = 0; b < NB; ++b) bk[b].init(B, n0, d.N, t);
@@ -592,11 +634,11 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // the x_t / x_lag seam, a ragged last row tile) per-thread pointers to clamped rows; workgroup-uniform choice
     const bool pl_a_aff = am.affine && am.all_rows, pl_b_aff = bm.affine && bm.all_rows;
     auto glds_stage = [&](int64_t k0, int buf, int part = 3) {   // part: 1 = A operand, 2 = B operand(s)
-        if constexpr (PL != 0) {
+        if constexpr (PRE) {
             const unsigned l0 = ldsw + (unsigned)(buf * STAGE) * 4u;
             float* b = lds + buf * STAGE;
             if (part & 1) {
-                const int64_t ka = PA ? k0 / 2 : k0;   // float offset inside a row
+                const int64_t ka = (PL & 1) ? k0 / 2 : k0;   // float offset inside a row
 #pragma unroll
                 for (int q = 0; q < NPA; ++q) {
                     if (pl_a_aff) am.glds_affine(am.tile_base(A, m0_ld, ka) + q * A.pstride, l0 + (unsigned)(q * TM * KF) * 4u);
@@ -604,7 +646,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 }
             }
             if (part & 2) {
-                const int64_t kb = PB ? k0 / 2 : k0;
+                const int64_t kb = (PL & 2) ? k0 / 2 : k0;
 #pragma unroll
                 for (int q = 0; q < NPB; ++q) {
                     if (pl_b_aff) bm.glds_affine(bm.tile_base(B, n0, kb) + q * B.pstride, l0 + (unsigned)(A_SZ + q * TN * KF) * 4u);
@@ -664,9 +706,14 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         }
     };
     auto store_stage = [&](float* buf) {
-        if constexpr (A_MM) am.store(buf, t);
-        else ak.store(buf, t);
-        if constexpr (B_MM) bm.store(buf + A_SZ, t);
+        if constexpr (A_MM) {
+            if constexpr (PSA) am.store_planes(buf, t);
+            else am.store(buf, t);
+        } else ak.store(buf, t);
+        if constexpr (B_MM) {
+            if constexpr (PSB) bm.store_planes(buf + A_SZ, t);
+            else bm.store(buf + A_SZ, t);
+        }
         else {
             bk[0].store(buf + A_SZ, t);
             if constexpr (NB == 2) bk[1].store(buf + A_SZ + B_SZ, t);
@@ -971,7 +1018,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // no reason to wait on the vector-memory counter inside the MFMA phase.  Whatever remains -- the
     // ragged last stage of such a workgroup, or every stage of an edge tile / scalar-load / covariance
     // shift workgroup -- runs the register-staged loop behind it.
-    const bool dense_ok = PL != 0 || (nst > 0 && stage_dense(k_begin) && affine_all());
+    const bool dense_ok = PRE || (!(PSA || PSB) && nst > 0 && stage_dense(k_begin) && affine_all());   // split-at-store: every stage through registers
     const int64_t nfull = dense_ok ? (k_end - k_begin) / KB : 0;
     if (nfull > 0) {
         const int64_t nst = nfull;   // stages of the ring loop
@@ -1172,7 +1219,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         DCV_STAMP_RT(5);
     }
     const int64_t k_rem = k_begin + nfull * KB;
-    const int64_t nrem = PL != 0 ? 0 : (k_end - k_rem + KB - 1) / KB;
+    const int64_t nrem = PRE ? 0 : (k_end - k_rem + KB - 1) / KB;
     if (nrem > 0) {
         resolve_stage(k_rem);
         load_stage(k_rem);

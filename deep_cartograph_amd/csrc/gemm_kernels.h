@@ -578,7 +578,27 @@ static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64
 #else
     using Big = CfgBigT<S>;
 #endif
-    switch (pick_cfg<MODE, Epi::kHead>(M, N, K, k_chunk)) {
+    const CfgPick pick = pick_cfg<MODE, Epi::kHead>(M, N, K, k_chunk);
+#ifdef DCV_PS_EXPERIMENT   // tools/planes_bench only: measured SLOWER than the LDS-DMA ring + in-register split
+    if constexpr (S && MODE != kTN) {
+        // Small grids of the split flavour (the row-parallel products of a small batch: one or two workgroups per CU) are
+        // bound by the vector ALU's operand splitting: stage through registers and split once per workgroup on the way to
+        // LDS (TileCfg::PL bits 2 / 3) -- both operands of an NT product, the A operand of an NN product.  Bit-identical
+        // results, half the splitting work -- and 25.2 vs 22.4 us at 8192 x 256 x 512, 12.0 vs 10.5 us at 8202 x 128 x 256:
+        // the register-staged loop exposes the load latency the DMA ring hides.
+        constexpr int PS = MODE == kNT ? 12 : 4;
+        static const bool ps_on = [] { const char* e = getenv("DCV_SPLIT_AT_STORE"); return !(e && e[0] == '0'); }();
+        if (ps_on && K % 32 == 0) {
+            if (pick == kPickHalfM || (pick == kPickQuarter && Epi::kHead))
+                return launch_gemm_cfg<MODE, TileCfg<2, 2, 1, 2, 32, 2, true, PS>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+            if (pick == kPickNarrowM) return launch_gemm_cfg<MODE, TileCfg<1, 4, 1, 1, 32, 2, true, PS>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+            if constexpr (!Epi::kHead) {
+                if (pick == kPickQuarter) return launch_gemm_cfg<MODE, TileCfg<2, 2, 1, 1, 32, 2, true, PS>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
+            }
+        }
+    }
+#endif
+    switch (pick) {
         case kPickNarrowN: return launch_gemm_cfg<MODE, CfgNarrowNT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
         case kPickNarrowM: return launch_gemm_cfg<MODE, CfgNarrowMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
         case kPickHalfM: return launch_gemm_cfg<MODE, CfgHalfMT<S>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
@@ -676,6 +696,10 @@ template <int PL> using CfgPlBig = TileCfg<2, 2, 2, 2, PL == 3 ? 16 : 32, PL == 
 #define DCV_PLH_NBUF 2
 #endif
 template <int PL> using CfgPlHalf = TileCfg<2, 2, 1, 2, 32, DCV_PLH_NBUF, true, PL>;
+#ifndef DCV_PLQ_NBUF
+#define DCV_PLQ_NBUF 2
+#endif
+template <int PL> using CfgPlQuarter = TileCfg<2, 2, 1, 1, 32, DCV_PLQ_NBUF, true, PL>;   // 64 x 64: two workgroups per CU on a small grid
 
 // NT product with plane operands: C[M,N] = A[M,K] . B[N,K]^T.  Returns DCV_EINVAL-free "not applicable" (1) when the
 // shape or the operands do not qualify -- the caller then takes the fp32-operand kernel -- and a DCV_E* (< 0) on error.
@@ -707,7 +731,11 @@ static int launch_gemm_planes(const Operand& A, const Operand& B, int64_t M, int
 #ifdef DCV_PL_FORCE_BIG
     return go(CfgPlBig<PL>{});
 #endif
-    if (cdiv(M, 128) * cdiv(N, 128) < want) return go(CfgPlHalf<PL>{});
+    if (cdiv(M, 128) * cdiv(N, 128) < want) {
+        // between one and two 64 x 128 workgroups per CU: 64 x 64 tiles, as the fp32-operand kernels choose (pick_cfg)
+        if (cdiv(M, 64) * cdiv(N, 128) < want && cdiv(M, 64) * cdiv(N, 128) >= want / 2 && N % 64 == 0) return go(CfgPlQuarter<PL>{});
+        return go(CfgPlHalf<PL>{});
+    }
     return go(CfgPlBig<PL>{});
 }
 

@@ -687,6 +687,29 @@ __device__ __forceinline__ void tica_grad_wave(TicaWaveLds<D>& w, const double* 
     if (lane == 0) *log_count = slot + 1;
 }
 
+// the wave-parallel loss head as a launch of its own: the data-parallel path, where the batch statistics are all-reduced
+// between the statistics kernel and the head (the single-thread form above is a chain of ~2000 dependent float64
+// instructions, 8 us; this one ~3 us)
+template <int D>
+__global__ __launch_bounds__(64) void tica_grad_wave_kernel(const double* __restrict__ stats, double Bg, double reg, double* __restrict__ gradp,
+                                                            double* __restrict__ log, int* __restrict__ log_count, int log_cap, int log_width) {
+    __shared__ TicaWaveLds<D> s_head;
+    __shared__ double s_stats[2 * D + 2 * D * D];
+    if (threadIdx.x < 2 * D + 2 * D * D) s_stats[threadIdx.x] = stats[threadIdx.x];
+    wave_sync_lds();
+    tica_grad_wave<D>(s_head, s_stats, Bg, reg, gradp, log, log_count, log_cap, log_width, (int)threadIdx.x);
+}
+typedef void (*TicaGradWaveFn)(const double*, double, double, double*, double*, int*, int, int);
+static TicaGradWaveFn tica_grad_wave_fn(int d) {
+    switch (d) {
+        case 1: return tica_grad_wave_kernel<1>;
+        case 2: return tica_grad_wave_kernel<2>;
+        case 3: return tica_grad_wave_kernel<3>;
+        case 4: return tica_grad_wave_kernel<4>;
+        default: return nullptr;
+    }
+}
+
 // The same statistics for D <= 4 outputs with every thread at work: a thread walks whole rows (its pair's
 // 2 D values, 2 D + 2 D^2 float64 accumulators in registers), waves combine by shuffles, the block through
 // LDS.  rows_per_block pairs per block (a multiple of 256; stats_plan): enough blocks to spread a small batch over
@@ -1856,8 +1879,13 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     bool fused_head = false;
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
         if (!m->head_done) {
-            hipLaunchKernelGGL(tica_grad_fn(m->d_out), dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
-                               train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
+            if (TicaGradWaveFn wf = tica_grad_wave_fn(m->d_out)) {
+                hipLaunchKernelGGL(wf, dim3(1), dim3(64), 0, s, (const double*)m->stats, (double)global_batch, m->desc.tica_reg,
+                                   train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
+            } else {
+                hipLaunchKernelGGL(tica_grad_fn(m->d_out), dim3(1), dim3(64), 0, s, m->stats, m->d_out, (double)global_batch, m->desc.tica_reg,
+                                   train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
+            }
             DCV_CHECK_LAUNCH();
         }
         m->head_done = false;

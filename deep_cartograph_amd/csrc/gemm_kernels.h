@@ -733,7 +733,9 @@ static int launch_gemm_planes(const Operand& A, const Operand& B, int64_t M, int
 #endif
     if (cdiv(M, 128) * cdiv(N, 128) < want) {
         // between one and two 64 x 128 workgroups per CU: 64 x 64 tiles, as the fp32-operand kernels choose (pick_cfg)
+#ifndef DCV_NO_PLQ
         if (cdiv(M, 64) * cdiv(N, 128) < want && cdiv(M, 64) * cdiv(N, 128) >= want / 2 && N % 64 == 0) return go(CfgPlQuarter<PL>{});
+#endif
         return go(CfgPlHalf<PL>{});
     }
     return go(CfgPlBig<PL>{});

@@ -285,6 +285,8 @@ struct MMajorStage {
         return op.p + op.rows.template get<false>(m0) * op.ld + k0;
     }
     __device__ __forceinline__ void glds_affine(const float* base, unsigned lds0) const {
+        // a tile shape with another unit count would silently issue NO copy here (a 256-row tile: 8 units per thread)
+        static_assert(UNITS % 256 != 0 || PER == 1 || PER == 2 || PER == 4, "units per thread of the batched LDS-DMA form");
         if constexpr (UNITS % 256 == 0 && (PER == 1 || PER == 2 || PER == 4)) glds16_batch<PER>(base, voff, lds0);
     }
     __device__ __forceinline__ bool dense(int64_t k0, int64_t k_end) const { return VEC && all_rows && k0 + KB <= k_end; }
@@ -407,6 +409,8 @@ struct KMajorStage {
         return op.p + (op.rows.template get<false>(k0) + row_off) * op.ld + c0;
     }
     __device__ __forceinline__ void glds_affine(const float* base, unsigned lds0) const {
+        // a tile shape with another unit count would silently issue NO copy here (a 256-row tile: 8 units per thread)
+        static_assert(UNITS % 256 != 0 || PER == 1 || PER == 2 || PER == 4, "units per thread of the batched LDS-DMA form");
         if constexpr (UNITS % 256 == 0 && (PER == 1 || PER == 2 || PER == 4)) glds16_batch<PER>(base, voff, lds0);
     }
     __device__ __forceinline__ void resolve(const Operand& op, int64_t k0, int64_t k_end, int64_t row_off, int t) {

@@ -595,7 +595,7 @@ class HTICACalculator(LinearCalculator):
 # ======================================================================================= neural
 # torch.optim defaults of the optimisers the HIP engine implements (torch 2.x signatures)
 _OPTIMIZERS = {
-    "Adam": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False),
+    "Adam": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, decoupled_weight_decay=False),
     "AdamW": dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False),
     "SGD": dict(lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False),
     "RMSprop": dict(lr=1e-2, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False),
@@ -611,7 +611,9 @@ _OPTIMIZERS = {
 # LBFGS re-evaluates the loss through a closure several times per step (not a per-element update), SparseAdam rejects
 # the dense gradients of these models inside torch itself (the reference's try fails there too)
 _OPTIMIZERS_REFUSED = {"LBFGS": "needs a closure that re-evaluates the model several times per step",
-                       "SparseAdam": "torch.optim.SparseAdam does not support dense gradients (the reference's try fails as well)"}
+                       "SparseAdam": "torch.optim.SparseAdam does not support dense gradients (the reference's try fails as well)",
+                       "Adafactor": "not part of the reference's pinned torch 2.1.2 (environment_detailed.yml): its getattr fails there",
+                       "Muon": "not part of the reference's pinned torch 2.1.2 (environment_detailed.yml): its getattr fails there"}
 _IMPLEMENTATION_SWITCHES = ("foreach", "fused", "capturable", "differentiable")   # no effect on the arithmetic
 
 
@@ -763,6 +765,8 @@ class NonLinear(CVCalculator):
 
     @staticmethod
     def _engine_optimizer_kwargs(name: str, kw: Dict) -> Dict:
+        if name == "Adam" and kw.get("decoupled_weight_decay"):   # newer torch: Adam(decoupled_weight_decay=True) is AdamW's update
+            name = "AdamW"
         out = dict(optimizer=name, lr=float(kw["lr"]), weight_decay=float(kw.get("weight_decay", 0.0)))
         if "betas" in kw:
             out["betas"] = (float(kw["betas"][0]), float(kw["betas"][1]))

@@ -322,3 +322,45 @@ def test_calculators_refuse_cpu():
     calc = cv_calculators_map["pca"]({"dimension": 2, "features_normalization": "mean_std"}, "/tmp/x")
     with pytest.raises(DcvError):
         calc.set_training_matrix(np.zeros((10, 4), dtype=np.float32))
+
+
+def test_optimizer_table_matches_torch_signatures():
+    """`optimizer.name` / `kwargs` of the YAML reach `getattr(torch.optim, name)(**kwargs)` in the reference
+    (cv_calculator.py:1377-1380).  The calculators' table of optimisers (defaults, accepted keyword arguments) is checked
+    against the signatures of the torch.optim classes themselves, and the mapping onto the engine's descriptor is total:
+    every optimiser of the table has an engine id, and the two torch.optim classes outside it are refused by name."""
+    import inspect
+
+    import torch
+
+    from deep_cartograph_amd import _lib
+    from deep_cartograph_amd.cv_calculator import _IMPLEMENTATION_SWITCHES, _OPTIMIZERS, _OPTIMIZERS_REFUSED, NonLinear
+
+    for name, table in _OPTIMIZERS.items():
+        sig = inspect.signature(getattr(torch.optim, name).__init__)
+        for kw, default in table.items():
+            assert kw in sig.parameters, (name, kw)
+            d = sig.parameters[kw].default
+            if isinstance(default, tuple):
+                assert tuple(d) == default, (name, kw, d)
+            else:
+                assert d == default, (name, kw, d, default)
+        extra = set(sig.parameters) - set(table) - set(_IMPLEMENTATION_SWITCHES) - {"self", "params", "maximize"}
+        assert not extra, f"{name}: torch accepts {extra} which the table does not know"
+        assert name in _lib.OPTIMIZER
+        out = NonLinear._engine_optimizer_kwargs(name, dict(table))
+        assert out["optimizer"] == name and "lr" in out
+    assert NonLinear._engine_optimizer_kwargs("Adam", {**_OPTIMIZERS["Adam"], "decoupled_weight_decay": True, "weight_decay": 0.01})["optimizer"] == "AdamW"
+    assert set(_lib.OPTIMIZER) == set(_OPTIMIZERS)
+    torch_classes = {n for n in dir(torch.optim) if inspect.isclass(getattr(torch.optim, n)) and issubclass(getattr(torch.optim, n), torch.optim.Optimizer)
+                     and n != "Optimizer"}
+    assert not (torch_classes - set(_OPTIMIZERS) - set(_OPTIMIZERS_REFUSED)), torch_classes   # every class of the installed torch is either run or refused by name
+
+
+def test_layer_options_carry_batchnorm():
+    """`batchnorm` / `last_layer_batchnorm` (yaml_schemas/train_colvars.py:24-31) become one flag per Linear."""
+    from deep_cartograph_amd.cv_calculator import NonLinear
+
+    act, drop, bn = NonLinear._layer_options({"layers": [8, 4], "activation": ["tanh", "relu"], "batchnorm": [True, False], "dropout": [0.1, None],
+                                              "last_layer_batchnorm": True, "last_layer_activation": None}, 2)
+    assert act == ["tanh", "relu", None] and drop == [0.1, 0.0, 0.0] and bn == [True, False, True]

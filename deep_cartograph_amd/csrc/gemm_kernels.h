@@ -566,7 +566,8 @@ static CfgPick pick_cfg(int64_t M, int64_t N, int64_t K, int64_t k_chunk) {
         // split-K product on a small grid (weight gradients of a small batch: the split count is bounded by the rows):
         // four times the workgroups with 64 x 64 tiles (measured on the 128 x 256 x 8202 product: 17.2 -> 10.6 us)
         const int64_t nsplit = cdiv(K, k_chunk > 0 ? k_chunk : K);
-        if (cdiv(M, 128) * cdiv(N, 128) * nsplit < (int64_t)num_cus() / 2) return kPickQuarter;
+        // (measured on the 256 x 512 x 8202 product: 16 chunks, 128 workgroups of 128 x 128 32.5 us, 512 of 64 x 64 21.9 us)
+        if (cdiv(M, 128) * cdiv(N, 128) * nsplit <= (int64_t)num_cus() / 2) return kPickQuarter;
     }
     return kPickBig;
 }
@@ -619,6 +620,16 @@ static int launch_gemm(const Operand& A, const Operand& B, int64_t M, int64_t N,
     return launch_gemm_mode<MODE, false, Epi>(A, B, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
 #endif
 }
+
+// The engine's products as plain functions, one translation unit per epilogue (inst_*.hip) so that the build compiles
+// them in parallel; each is launch_gemm<MODE, Epi> of the named epilogue.
+int gemm_nt_bias_act(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const EpiBiasAct& epi, hipStream_t s, const TailWs* tw);
+int gemm_nt_head4(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const EpiBiasActHead<4>& epi, hipStream_t s, const TailWs* tw);
+int gemm_nt_head8(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const EpiBiasActHead<8>& epi, hipStream_t s, const TailWs* tw);
+int gemm_tn_slab(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk, const EpiSlab& epi, hipStream_t s);
+int gemm_nn_act_grad(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const EpiActGrad& epi, hipStream_t s,
+                     int* tiles_m_out, const TailWs* tw);
+int gemm_nn_store(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const EpiStore& epi, hipStream_t s);
 
 // Weight gradient (TN, slabs) and input gradient (NN) of one layer as ONE launch (wgrad_dgrad_kernel; defined in
 // pair.hip).  Returns 1 when the pair form does not apply (the caller then launches the two products one after the

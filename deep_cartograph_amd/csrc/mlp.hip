@@ -1191,9 +1191,23 @@ static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t*
     int64_t want = cdiv(2 * (int64_t)num_cus(), tiles);
     int64_t max_by_rows = cdiv(rows, 256);
     if (want > max_by_rows) {
-        // row-limited (small batches): a split count that is a multiple of 8 keeps tiles x splits on whole multiples of
-        // the CU count (33 splits x 8 tiles = 264 workgroups cost 1.6 x of 256: the 8 extra share SIMDs with 8 others)
-        // and lets the XCD-aware map pair the tiles of a chunk
+        // row-limited (small batches).  When 64 x 64 tiles reach two workgroups per CU with a split count the rows allow,
+        // take them (pick_cfg<kTN> follows: fewer than one 128 x 128 workgroup per CU): measured on the 256 x 512 x 8202
+        // product, 16 chunks of 64 x 64 tiles 21.9 us against 29 chunks of 128 x 128 tiles 23.7 -- and 16 slabs instead of
+        // 29 to write and reduce; a multiple of 8 chunks lets the XCD map keep a chunk's rows in one L2.
+        const int64_t tiles_q = cdiv(out, 64) * cdiv(in, 64);
+        const int64_t want_q = cdiv(cdiv(2 * (int64_t)num_cus(), tiles_q), 8) * 8;
+        if (out > 32 && in > 32 && want_q <= max_by_rows) {
+            int64_t kc = cdiv(cdiv(rows, want_q), 32) * 32;
+            if (cdiv(rows, kc) % 8 != 0) kc = cdiv(rows, want_q);   // ragged chunk ends (the stage tail goes through registers)
+            if (tiles * cdiv(rows, kc) <= (int64_t)num_cus() / 2) {   // pick_cfg<kTN>'s condition for 64 x 64 tiles
+                *k_chunk = kc;
+                *splits = cdiv(rows, kc);
+                return;
+            }
+        }
+        // otherwise a split count that is a multiple of 8 keeps tiles x splits on whole multiples of the CU count (33
+        // splits x 8 tiles = 264 workgroups cost 1.6 x of 256: the 8 extra share SIMDs with 8 others)
         want = max_by_rows >= 8 ? max_by_rows / 8 * 8 : max_by_rows;
     }
     if (want < 1) want = 1;
@@ -1649,11 +1663,11 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             if (nx.out <= 4) {
                 EpiBiasActHead<4> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
                 epi.drop = drop_cfg(m, l);
-                rc = launch_gemm<kNT, EpiBiasActHead<4>>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
+                rc = gemm_nt_head4(A, B, rows, p.out, p.in, epi, s, &m->tail);
             } else {
                 EpiBiasActHead<8> epi{p.H, p.ldh, m->params + p.b_off, p.act, vec, m->params + nx.w_off, nx.in, m->params + nx.b_off, nx.out, nx.act, nx.H, nx.ldh};
                 epi.drop = drop_cfg(m, l);
-                rc = launch_gemm<kNT, EpiBiasActHead<8>>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
+                rc = gemm_nt_head8(A, B, rows, p.out, p.in, epi, s, &m->tail);
             }
             if (rc) return rc;
             prof_mark(m, l, 0, 1, s);
@@ -1673,7 +1687,7 @@ static int run_forward(dcv_mlp* m, const float* Xn, int64_t ld, const RowMap& ro
             epi.mask = nullptr;
             p.mask_rows = -1;
         }
-        int rc = launch_gemm<kNT, EpiBiasAct>(A, B, rows, p.out, p.in, 0, epi, s, nullptr, &m->tail);
+        int rc = gemm_nt_bias_act(A, B, rows, p.out, p.in, epi, s, &m->tail);
         if (rc) return rc;
         if (p.bn) {
             // training: batch statistics of every forward call of the step -- a Deep-TICA batch is two (x_t rows, then x_lag
@@ -2003,7 +2017,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         rd.bblocks = bblocks;
         if (l == 0) {
             prof_mark(m, l, 1, 0, s);
-            int rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
+            int rc = gemm_tn_slab(A, B, p.out, p.in, R, kc, epi, s);
             if (rc) return rc;
             prof_mark(m, l, 1, 1, s);
             continue;
@@ -2031,11 +2045,11 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         int rc = launch_wgrad_dgrad(A, B, p.out, p.in, R, kc, epi, Ad, Bd, R, p.in, p.out, eg, &bblocks, &m->tail, s);
         if (rc < 0) return rc;
         if (rc == 1) {
-            rc = launch_gemm<kTN, EpiSlab>(A, B, p.out, p.in, R, kc, epi, s);
+            rc = gemm_tn_slab(A, B, p.out, p.in, R, kc, epi, s);
             if (rc) return rc;
             prof_mark(m, l, 1, 1, s);
             prof_mark(m, l, 2, 0, s);
-            rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, R, p.in, p.out, 0, eg, s, &bblocks, &m->tail);
+            rc = gemm_nn_act_grad(Ad, Bd, R, p.in, p.out, eg, s, &bblocks, &m->tail);
             if (rc) return rc;
             prof_mark(m, l, 2, 1, s);
         } else {
@@ -2414,7 +2428,7 @@ extern "C" int dcv_mlp_input_sensitivity(dcv_mlp* m, const float* Xn_d, int64_t 
         Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
         EpiActGrad eg{dz_nxt, m->ld_dz, q.H, q.ldh, q.bn ? DCV_ACT_NONE : q.act, q.bpart, q.out, quad_ok(dz_nxt, m->ld_dz) && quad_ok(q.H, q.ldh)};
         int bblocks = 0;
-        rc = launch_gemm<kNN, EpiActGrad>(Ad, Bd, n, p.in, p.out, 0, eg, s, &bblocks);
+        rc = gemm_nn_act_grad(Ad, Bd, n, p.in, p.out, eg, s, &bblocks, nullptr);
         if (rc) return rc;
         if (q.bn) {
             rc = bn_eval_backward(m, l - 1, dz_nxt, m->ld_dz, n, q.act, s);
@@ -2431,7 +2445,7 @@ extern "C" int dcv_mlp_input_sensitivity(dcv_mlp* m, const float* Xn_d, int64_t 
         Operand Ad = make_operand(dz_cur, m->ld_dz, p.out);
         Operand Bd = make_operand(m->params + p.w_off, p.in, p.in);
         EpiStore es{G, F, quad_ok(G, F)};
-        rc = launch_gemm<kNN, EpiStore>(Ad, Bd, n, p.in, p.out, 0, es, s);
+        rc = gemm_nn_store(Ad, Bd, n, p.in, p.out, es, s);
         if (rc) return rc;
     }
     const int nb = (int)cdiv(n, kAbsRows);

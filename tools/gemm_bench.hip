@@ -139,6 +139,23 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    if (argc > 3 && !strcmp(argv[3], "wgrad")) {   // L0 weight gradient: tile shape x split count (chunk lengths need not be stage multiples)
+        Operand A = make_operand(dZ, H1, H1), B = make_operand(X, F, F);
+        EpiSlab epi{slab, H1, F, 1, 0, true, slab_cap};
+        for (int64_t ns : {8, 16, 24, 29, 32, 40, 48, 64}) {
+            const int64_t kc = (R + ns - 1) / ns;
+            const int64_t kc32 = (kc + 31) / 32 * 32;
+            for (int64_t c : {kc, kc32}) {
+                if (c == kc32 && kc32 == kc) continue;
+                double b = time_ms([&] { launch_gemm_cfg<kTN, CfgBigT<true>, 1, EpiSlab>(A, B, 0, H1, F, R, c, epi, s, nullptr, nullptr); }, it);
+                double h = time_ms([&] { launch_gemm_cfg<kTN, CfgHalfMT<true>, 1, EpiSlab>(A, B, 0, H1, F, R, c, epi, s, nullptr, nullptr); }, it);
+                double q = time_ms([&] { launch_gemm_cfg<kTN, CfgQuarterT<true>, 1, EpiSlab>(A, B, 0, H1, F, R, c, epi, s, nullptr, nullptr); }, it);
+                printf("L0 wgrad want %2lld kc=%5lld splits=%3lld : 128x128 %6.1f us | 64x128 %6.1f us | 64x64 %6.1f us\n", (long long)ns, (long long)c,
+                       (long long)((R + c - 1) / c), b * 1e3, h * 1e3, q * 1e3);
+            }
+        }
+        return 0;
+    }
     {   // L0 forward: [R,512] x [256,512]^T
         // DCV_LDPAD / DCV_LDPADW: floats added to the row pitch of X / W1 (<= 64): a 2 KiB pitch puts the 128-byte row
         // segments of a stage on very few L2 channels

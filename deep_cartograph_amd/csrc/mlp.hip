@@ -88,9 +88,9 @@ struct OptArgs {
     float decay;      // AdamW: 1 - lr * weight_decay
     float p0, p1, p2, p3;   // further per-step scalars of Adamax / NAdam / RAdam / Adadelta / ASGD / Rprop (next_opt_args)
 };
-__device__ __forceinline__ void opt_update(int64_t i, float gi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
-                                           float* __restrict__ s3, const OptArgs& a) {
-    float pi = p[i];
+// pi = p[i], loaded by the caller (the reduction kernels issue that load before they wait for the partial sums)
+__device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                             float* __restrict__ s3, const OptArgs& a) {
     switch (a.kind) {
         case DCV_OPT_ADAM:
         case DCV_OPT_ADAMW: {
@@ -218,6 +218,10 @@ __device__ __forceinline__ void opt_update(int64_t i, float gi, float* __restric
         }
     }
 }
+__device__ __forceinline__ void opt_update(int64_t i, float gi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
+                                           float* __restrict__ s3, const OptArgs& a) {
+    opt_update_p(i, gi, p[i], p, s1, s2, s3, a);
+}
 __global__ __launch_bounds__(256) void optimizer_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
                                                         float* __restrict__ s2, float* __restrict__ s3, int64_t n, OptArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) opt_update(i, g[i], p, s1, s2, s3, a);
@@ -299,6 +303,84 @@ __global__ __launch_bounds__(256) void reduce_grads_small_kernel(ReduceArgs a, f
         }
         __syncthreads();
     }
+}
+
+// The small-split reduction on a flat grid with 16-byte loads.  The weights and the biases of every entry are separate
+// items {partials, count, number of partials}; the grid is the concatenation of the items' blocks (no empty workgroups
+// for the narrow layers).  A block of 256 threads covers 1024 / G consecutive elements with G groups of threads, group g
+// taking the partials q = g, g + G, ... (four consecutive elements per thread: one global_load_dwordx4 per partial
+// where the item allows); G = 4 for few partials, 16 when an item has more than 32 (the 129 bias partials of the
+// 64-row tiles, the 257 of the fused last-layer pass: walked by 4 groups they are a chain of 64 dependent-latency
+// loads, the longest path of the launch).  After the exchange every thread of the first 1024 / G finishes ONE element,
+// groups combined in order, float64: deterministic -- and its parameter load was issued before the partials were
+// waited for.
+struct QuadItem {
+    const float* src;   // [parts][count]
+    int64_t dst;        // offset of element 0 in grads / params
+    int count, parts;
+    int blk0;           // first block of this item in the grid
+    int groups;         // G
+};
+struct QuadArgs {
+    QuadItem it[4 * DCV_MAX_LAYERS];
+    int n;
+};
+inline int quad_groups(int parts) { return parts > 32 ? 16 : 4; }
+template <int G>
+__device__ __forceinline__ void reduce_quad_block(const QuadItem& d, int blk, float* __restrict__ grads, float scale, int fuse,
+                                                  float* __restrict__ params, float* __restrict__ s1, float* __restrict__ s2,
+                                                  float* __restrict__ s3, const OptArgs& oa, double* s_red) {
+    constexpr int EPB = 1024 / G, TPG = EPB / 4;   // elements per block, threads per group
+    const int t = threadIdx.x, g = t / TPG, sub = t % TPG;
+    const int base = blk * EPB;
+    const int mine = base + t;
+    const bool fin = t < EPB && mine < d.count;
+    float pi = 0.f;
+    if (fuse && fin) pi = params[d.dst + mine];
+    const int e0 = base + 4 * sub;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (e0 + 4 <= d.count && (d.count & 3) == 0 && (reinterpret_cast<uintptr_t>(d.src) & 15) == 0) {
+        const float* p = d.src + e0;
+#pragma unroll 8
+        for (int q = g; q < d.parts; q += G) {
+            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)q * d.count);
+            acc[0] += (double)v.x;
+            acc[1] += (double)v.y;
+            acc[2] += (double)v.z;
+            acc[3] += (double)v.w;
+        }
+    } else if (e0 < d.count) {
+        const float* p = d.src + e0;
+        const int nv = d.count - e0 < 4 ? d.count - e0 : 4;
+#pragma unroll 4
+        for (int q = g; q < d.parts; q += G) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nv) acc[j] += (double)p[(int64_t)q * d.count + j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s_red[g * EPB + 4 * sub + j] = acc[j];
+    __syncthreads();
+    if (fin) {
+        double tot = s_red[t];
+#pragma unroll
+        for (int k = 1; k < G; ++k) tot += s_red[k * EPB + t];
+        const float gr = (float)(tot * (double)scale);
+        grads[d.dst + mine] = gr;
+        if (fuse) opt_update_p(d.dst + mine, gr, pi, params, s1, s2, s3, oa);
+    }
+}
+__global__ __launch_bounds__(256) void reduce_grads_quad_kernel(QuadArgs a, float* __restrict__ grads, float scale, int fuse,
+                                                                float* __restrict__ params, float* __restrict__ s1,
+                                                                float* __restrict__ s2, float* __restrict__ s3, OptArgs oa) {
+    __shared__ double s_red[1024];
+    int l = 0;
+    while (l + 1 < a.n && (int)blockIdx.x >= a.it[l + 1].blk0) ++l;   // uniform
+    const QuadItem& d = a.it[l];
+    const int blk = (int)blockIdx.x - d.blk0;
+    if (d.groups == 16) reduce_quad_block<16>(d, blk, grads, scale, fuse, params, s1, s2, s3, oa, s_red);
+    else reduce_quad_block<4>(d, blk, grads, scale, fuse, params, s1, s2, s3, oa, s_red);
 }
 
 // ------------------------------------------------------------------ Deep-TICA batch statistics
@@ -1850,7 +1932,28 @@ static int launch_reduce(dcv_mlp* m, const ReduceArgs& ra_all, int l0, int l1, b
     for (int l = l0; l < l1; ++l)
         if (m->layers[l].bn) take(ra_all.l[m->L + l]);   // weight / bias of the batch normalisation behind layer l
     if (ra.L <= 0) return DCV_OK;
-    if (max_splits <= 512 && max_bblocks <= 1024) {   // few partials per weight (the few bias elements may see more)
+    static const bool quad_off = [] { const char* e = getenv("DCV_REDUCE_QUAD"); return e && e[0] == '0'; }();
+    if (max_splits <= 512 && max_bblocks <= 1024 && !quad_off) {
+        QuadArgs qa;
+        qa.n = 0;
+        int64_t blocks = 0;
+        auto item = [&](const float* src, int64_t dst, int64_t count, int parts) {
+            if (count <= 0) return;
+            if (!src || parts < 0) parts = 0;   // no partials: a zero gradient, as the other two kernels give
+            QuadItem& q = qa.it[qa.n++];
+            q = QuadItem{src, dst, (int)count, parts, (int)blocks, quad_groups(parts)};
+            blocks += cdiv(count, 1024 / q.groups);
+        };
+        for (int l = 0; l < ra.L; ++l) {
+            DCV_REQUIRE(ra.l[l].w_count < (1ll << 31), "reduce: layer too large");
+            item(ra.l[l].slab, ra.l[l].w_off, ra.l[l].w_count, ra.l[l].splits);
+            item(ra.l[l].bpart, ra.l[l].b_off, ra.l[l].out, ra.l[l].bblocks);
+        }
+        if (blocks <= 0) return DCV_OK;
+        DCV_REQUIRE(blocks < (1ll << 31), "reduce: grid out of range");
+        hipLaunchKernelGGL(reduce_grads_quad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qa, m->grads, 1.f, fuse_opt ? 1 : 0, m->params,
+                           m->adam_m, m->adam_v, m->opt_aux, oa);
+    } else if (max_splits <= 512 && max_bblocks <= 1024) {   // few partials per weight (the few bias elements may see more)
         int64_t bx = cdiv(max_total, 64);
         if (bx > 2048) bx = 2048;
         hipLaunchKernelGGL(reduce_grads_small_kernel, dim3((unsigned)bx, ra.L), dim3(256), 0, s, ra, m->grads, 1.f, fuse_opt ? 1 : 0, m->params,

@@ -346,16 +346,25 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
             {
                 const int nti = y.nk_in, ntot = y.nk_out * nti;
                 float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.out * y.in;
+                const bool vec_ok = (y.in & 3) == 0 && ((y.pw_off + (int64_t)blockIdx.x * y.out * y.in) & 3) == 0;   // a.part is a hipMalloc base
                 int ot = 0, it = wave;
                 while (it >= nti) { it -= nti; ++ot; }
 #pragma unroll 2
                 for (int tile = wave; tile < ntot; tile += kSnetWaves) {
-                    const sv4f acc = snet_wgrad_tile<TR>(dZ + q * psz + ot * 16 + n, psz, Hin + q * psh + it * 16 + n, psh);
-                    const int i = it * 16 + n;
+                    // operands swapped (rows of the MFMA tile = input columns): a lane ends up with four CONSECUTIVE inputs
+                    // i of one output o = its 16 bytes of the partial's row -- one global_store_dwordx4 per tile and lane
+                    // instead of four 4-byte stores (the partial stores of the two wide layers were what these phases waited on)
+                    const sv4f acc = snet_wgrad_tile<TR>(Hin + q * psh + it * 16 + n, psh, dZ + q * psz + ot * 16 + n, psz);
+                    const int o = ot * 16 + n, i0 = it * 16 + 4 * q;
+                    if (o < y.out) {
+                        float* dst = pw + (int64_t)o * y.in + i0;
+                        if (vec_ok && i0 + 4 <= y.in) {
+                            *reinterpret_cast<sv4f*>(dst) = acc;
+                        } else {
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int o = ot * 16 + 4 * q + v;
-                        if (o < y.out && i < y.in) pw[(int64_t)o * y.in + i] = acc[v];
+                            for (int v = 0; v < 4; ++v)
+                                if (i0 + v < y.in) dst[v] = acc[v];
+                        }
                     }
                     it += kSnetWaves;
                     while (it >= nti) { it -= nti; ++ot; }
@@ -548,22 +557,23 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
     const int64_t nwg = cdiv(R, pl->TR);
     if (nwg > m->spart_blocks || nwg * pl->per_wg * (int64_t)sizeof(float) > kMaxPartBytes || nwg > 512) return 1;   // large batches: the tiled products are the better engine
-    if (train && pl->part_floats < nwg * pl->per_wg) {
+    const int64_t part_need = nwg * pl->per_wg + 8 * (int64_t)m->L;   // + the alignment padding of the items
+    if (train && pl->part_floats < part_need) {
         if (pl->part) (void)hipFree(pl->part);
         pl->part = nullptr;
         pl->part_floats = 0;
-        if (hipMalloc(reinterpret_cast<void**>(&pl->part), (size_t)(nwg * pl->per_wg) * sizeof(float)) != hipSuccess) {
+        if (hipMalloc(reinterpret_cast<void**>(&pl->part), (size_t)part_need * sizeof(float)) != hipSuccess) {
             (void)hipGetLastError();
             return 1;
         }
-        pl->part_floats = nwg * pl->per_wg;
+        pl->part_floats = part_need;
     }
     SnetArgs a = pl->base;
     int64_t off = 0;
     for (int l = 0; l < m->L; ++l) {
         SnetLayer& y = a.l[l];
-        y.pw_off = off; off += nwg * (int64_t)y.out * y.in;
-        y.pb_off = off; off += nwg * (int64_t)y.out;
+        y.pw_off = off; off += (nwg * (int64_t)y.out * y.in + 3) / 4 * 4;   // 16-byte aligned items (vector stores here, vector loads in the reduction)
+        y.pb_off = off; off += (nwg * (int64_t)y.out + 3) / 4 * 4;
         if (ra) {
             ra->slab[l] = pl->part + y.pw_off;
             ra->bpart[l] = pl->part + y.pb_off;

@@ -64,4 +64,6 @@ if os.environ.get("DCV_SNET_STAMPS") == "1":
             else:
                 nm = f"layer {k - 48}: wgrad tiles done"
             print(f"  stamp {k:2d} {nm:38s} +{(v[k] - t0) * 0.01:7.2f} us")
+    if v[12] and v[13]:
+        print(f"  shader clock over the kernel: {(v[13] - v[12]) / ((v[60] - v[0]) * 10.0):.3f} GHz (s_memtime / s_memrealtime)")
     eng.close()

@@ -123,6 +123,7 @@ struct GemmDims {
     int64_t k_chunk;  // TN: contraction rows per blockIdx.z (K for the others)
     int tiles_m, tiles_n;
     int xcd_remap;    // XCD-aware block -> tile map enabled (launch-time decision)
+    int wt;           // output rows leave as write-through (sc1) stores (launch-time decision: prepare_gemm)
     // Ragged last row tile of a row-parallel product (NT / NN) whose workgroup count just exceeds the CU count: that
     // tile's contraction is cut into tail_split chunks of k_chunk, one extra (short-lived) workgroup each, instead of
     // one full-length workgroup that would share a CU's SIMDs with a regular one for the whole launch.  Every chunk
@@ -1390,7 +1391,12 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
                 if (fast) {
 #pragma unroll
                     for (int q = 0; q < EQ; ++q) {
-                        *reinterpret_cast<float4*>(epi.out_ptr(0, mbase + r0 + (qc + q) * RPP, col)) = v[q];
+                        if (d.wt) {
+                            hv4f hv = {v[q].x, v[q].y, v[q].z, v[q].w};
+                            handoff_store16(epi.out_ptr(0, mbase + r0 + (qc + q) * RPP, col), hv);
+                        } else {
+                            *reinterpret_cast<float4*>(epi.out_ptr(0, mbase + r0 + (qc + q) * RPP, col)) = v[q];
+                        }
                         if constexpr (Epi::kColSum) {
                             cs.x += v[q].x; cs.y += v[q].y; cs.z += v[q].z; cs.w += v[q].w;
                         }

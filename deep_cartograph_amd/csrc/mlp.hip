@@ -89,6 +89,13 @@ struct OptArgs {
     float p0, p1, p2, p3;   // further per-step scalars of Adamax / NAdam / RAdam / Adadelta / ASGD / Rprop (next_opt_args)
 };
 // pi = p[i], loaded by the caller (the reduction kernels issue that load before they wait for the partial sums)
+// WT: write-through stores (the launch then ends without dirty lines to write back: reduce_grads_quad_kernel)
+template <bool WT>
+__device__ __forceinline__ void opt_st(float* p, float v) {
+    if constexpr (WT) handoff_store(p, v);
+    else *p = v;
+}
+template <bool WT = false>
 __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
                                              float* __restrict__ s3, const OptArgs& a) {
     switch (a.kind) {
@@ -102,43 +109,43 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             float vden = vi;
             if (a.flag) {                                                          // amsgrad: max_exp_avg_sq = max(., exp_avg_sq)
                 vden = fmaxf(s3[i], vi);
-                s3[i] = vden;
+                opt_st<WT>(s3 + i, vden);
             }
             const float denom = sqrtf(vden) / a.c2 + a.eps;
-            s1[i] = mi;
-            s2[i] = vi;
-            p[i] = pi - a.c1 * (mi / denom);                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+            opt_st<WT>(s1 + i, mi);
+            opt_st<WT>(s2 + i, vi);
+            opt_st<WT>(p + i, pi - a.c1 * (mi / denom));                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
             break;
         }
         case DCV_OPT_SGD: {
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             if (a.b1 != 0.f) {                                                     // b1 = momentum, w1 = 1 - dampening
                 float bi = a.first ? gi : s1[i] * a.b1 + a.w1 * gi;               // buf.mul_(momentum).add_(grad, alpha=1 - dampening)
-                s1[i] = bi;
+                opt_st<WT>(s1 + i, bi);
                 gi = a.flag ? fmaf(a.b1, bi, gi) : bi;                            // nesterov: grad.add(buf, alpha=momentum)
             }
-            p[i] = pi - a.lr * gi;
+            opt_st<WT>(p + i, pi - a.lr * gi);
             break;
         }
         case DCV_OPT_RMSPROP: {
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             float sq = s2[i] * a.b2 + a.w2 * gi * gi;                             // square_avg.mul_(alpha).addcmul_(grad, grad, 1 - alpha)
-            s2[i] = sq;
+            opt_st<WT>(s2 + i, sq);
             float avg;
             if (a.flag) {                                                          // centered
                 float ga = s3[i];
                 ga = ga + (gi - ga) * a.w2;                                        // grad_avg.lerp_(grad, 1 - alpha)
-                s3[i] = ga;
+                opt_st<WT>(s3 + i, ga);
                 avg = sqrtf(sq - ga * ga) + a.eps;                                 // addcmul(grad_avg, grad_avg, -1).sqrt_().add_(eps)
             } else {
                 avg = sqrtf(sq) + a.eps;
             }
             if (a.b1 > 0.f) {                                                      // b1 = momentum
                 const float bi = s1[i] * a.b1 + gi / avg;                          // buf.mul_(momentum).addcdiv_(grad, avg)
-                s1[i] = bi;
-                p[i] = pi - a.lr * bi;
+                opt_st<WT>(s1 + i, bi);
+                opt_st<WT>(p + i, pi - a.lr * bi);
             } else {
-                p[i] = pi - a.lr * (gi / avg);
+                opt_st<WT>(p + i, pi - a.lr * (gi / avg));
             }
             break;
         }
@@ -147,9 +154,9 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             float mi = s1[i];
             mi = mi + (gi - mi) * a.w1;                                           // exp_avg.lerp_(grad, 1 - beta1)
             const float ui = fmaxf(s2[i] * a.b2, fabsf(gi) + a.eps);              // maximum(exp_inf * beta2, |grad| + eps)
-            s1[i] = mi;
-            s2[i] = ui;
-            p[i] = pi - a.c1 * (mi / ui);                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
+            opt_st<WT>(s1 + i, mi);
+            opt_st<WT>(s2 + i, ui);
+            opt_st<WT>(p + i, pi - a.c1 * (mi / ui));                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
             break;
         }
         case DCV_OPT_NADAM: {    // _single_tensor_nadam: p0 = -lr (1 - mu) / (1 - mu_product), p1 = -lr mu_next / (1 - mu_product_next), c2 = 1 - beta2^t
@@ -161,10 +168,10 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             mi = mi + (gi - mi) * a.w1;
             vi = vi * a.b2 + a.w2 * gi * gi;
             const float denom = sqrtf(vi / a.c2) + a.eps;                          // exp_avg_sq.div(bias_correction2).sqrt().add(eps)
-            s1[i] = mi;
-            s2[i] = vi;
+            opt_st<WT>(s1 + i, mi);
+            opt_st<WT>(s2 + i, vi);
             pi = pi + a.p0 * (gi / denom);
-            p[i] = pi + a.p1 * (mi / denom);
+            opt_st<WT>(p + i, pi + a.p1 * (mi / denom));
             break;
         }
         case DCV_OPT_RADAM: {    // _single_tensor_radam: c1 = 1 - beta1^t, c2 = sqrt(1 - beta2^t), p0 = rect (0: rho_t <= 5)
@@ -175,11 +182,11 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             float mi = s1[i], vi = s2[i];
             mi = mi + (gi - mi) * a.w1;
             vi = vi * a.b2 + a.w2 * gi * gi;
-            s1[i] = mi;
-            s2[i] = vi;
+            opt_st<WT>(s1 + i, mi);
+            opt_st<WT>(s2 + i, vi);
             const float mhat = mi / a.c1;
-            if (a.p0 > 0.f) p[i] = pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0;
-            else p[i] = pi - mhat * a.lr;
+            if (a.p0 > 0.f) opt_st<WT>(p + i, pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0);
+            else opt_st<WT>(p + i, pi - mhat * a.lr);
             break;
         }
         case DCV_OPT_ADADELTA: { // _single_tensor_adadelta: s1 = square_avg, s2 = acc_delta, b2 = rho, w2 = 1 - rho
@@ -187,33 +194,33 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float sq = s1[i] * a.b2 + a.w2 * gi * gi;
             const float acc = s2[i];
             const float delta = sqrtf(acc + a.eps) / sqrtf(sq + a.eps) * gi;
-            s1[i] = sq;
-            s2[i] = acc * a.b2 + a.w2 * delta * delta;
-            p[i] = pi - a.lr * delta;
+            opt_st<WT>(s1 + i, sq);
+            opt_st<WT>(s2 + i, acc * a.b2 + a.w2 * delta * delta);
+            opt_st<WT>(p + i, pi - a.lr * delta);
             break;
         }
         case DCV_OPT_ASGD: {     // _single_tensor_asgd: p0 = 1 - lambd * eta, p1 = eta (the averaged copy ax is not kept)
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             pi = pi * a.p0;
-            p[i] = pi - a.p1 * gi;
+            opt_st<WT>(p + i, pi - a.p1 * gi);
             break;
         }
         case DCV_OPT_RPROP: {    // _single_tensor_rprop: s1 = prev, s2 = step_size; p0 / p1 = eta minus / plus, p2 / p3 = step bounds
             const float sg = gi * s1[i];
             const float f = sg > 0.f ? a.p1 : (sg < 0.f ? a.p0 : 1.f);
             const float st = fminf(fmaxf(s2[i] * f, a.p2), a.p3);
-            s2[i] = st;
+            opt_st<WT>(s2 + i, st);
             if (sg < 0.f) gi = 0.f;
             const float sgn = gi > 0.f ? 1.f : (gi < 0.f ? -1.f : 0.f);
-            p[i] = pi - sgn * st;
-            s1[i] = gi;
+            opt_st<WT>(p + i, pi - sgn * st);
+            opt_st<WT>(s1 + i, gi);
             break;
         }
         default: {   // DCV_OPT_ADAGRAD
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             const float su = s2[i] + gi * gi;                                      // state_sum.addcmul_(grad, grad, value=1)
-            s2[i] = su;
-            p[i] = pi - a.c1 * (gi / (sqrtf(su) + a.eps));                         // param.addcdiv_(grad, std, value=-clr)
+            opt_st<WT>(s2 + i, su);
+            opt_st<WT>(p + i, pi - a.c1 * (gi / (sqrtf(su) + a.eps)));                         // param.addcdiv_(grad, std, value=-clr)
             break;
         }
     }
@@ -367,8 +374,8 @@ __device__ __forceinline__ void reduce_quad_block(const QuadItem& d, int blk, fl
 #pragma unroll
         for (int k = 1; k < G; ++k) tot += s_red[k * EPB + t];
         const float gr = (float)(tot * (double)scale);
-        grads[d.dst + mine] = gr;
-        if (fuse) opt_update_p(d.dst + mine, gr, pi, params, s1, s2, s3, oa);
+        handoff_store(grads + d.dst + mine, gr);
+        if (fuse) opt_update_p<true>(d.dst + mine, gr, pi, params, s1, s2, s3, oa);
     }
 }
 __global__ __launch_bounds__(256) void reduce_grads_quad_kernel(QuadArgs a, float* __restrict__ grads, float scale, int fuse,
@@ -1067,7 +1074,7 @@ __global__ __launch_bounds__(256) void head_backward_kernel(const float* __restr
                 const float4 k = drop_prev.mult(r, c4 * 4);
                 z.x *= k.x; z.y *= k.y; z.z *= k.z; z.w *= k.w;
             }
-            *reinterpret_cast<float4*>(dZ + r * ldz + c4 * 4) = z;
+            handoff_store16(dZ + r * ldz + c4 * 4, hv4f{z.x, z.y, z.z, z.w});   // write-through: nothing to write back when the launch ends
             ab.x += z.x; ab.y += z.y; ab.z += z.z; ab.w += z.w;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                     if (o < y.out) {
                         float* dst = pw + (int64_t)o * y.in + i0;
                         if (vec_ok && i0 + 4 <= y.in) {
-                            *reinterpret_cast<sv4f*>(dst) = acc;
+                            handoff_store16(dst, acc);   // write-through: the 10 MB of partials are not left for the write-back at the launch's end (44.3 -> 42.8 us per step)
                         } else {
 #pragma unroll
                             for (int v = 0; v < 4; ++v)

@@ -29,8 +29,16 @@ for name, fn in (("eval", eng.eval_step), ("train", eng.train_step)):
     n = 2000
     for i in range(n):
         fn(X, row0=(i % 40) * bs, batch=bs)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
-    print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us/step (batch {bs}, DCV_SNET_TR={os.environ.get('DCV_SNET_TR', 'auto')})", flush=True)
+    tt = time.perf_counter()
+    for i in range(100):   # into an empty queue: the host's own cost per step
+        fn(X, row0=(i % 40) * bs, batch=bs)
+    t_host = (time.perf_counter() - tt) / 100
+    torch.cuda.synchronize()
+    print(f"{name}: host cost of 100 enqueues into an empty queue {t_host * 1e6:.1f} us/step")
+    print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us/step (batch {bs}, DCV_SNET_TR={os.environ.get('DCV_SNET_TR', 'auto')}); "
+          f"host enqueue alone {t_enq / n * 1e6:.1f} us/step", flush=True)
 eng.close()
 
 if os.environ.get("DCV_SNET_STAMPS") == "1":

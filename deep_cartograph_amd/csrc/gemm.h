@@ -152,6 +152,12 @@ struct TileCfg {
     static constexpr bool SPLIT = SPLIT_;
     static constexpr int PL = PL_;
     static_assert(PL == 0 || SPLIT, "plane operands belong to the split flavour");
+    // bit 4 (with bits 2 / 3, NT products): the fp32 stage arrives by LDS-DMA in a raw ring behind the plane buffers and is
+    // split from THERE, once per workgroup (gemm_block: the LS loop).  Bit-identical, half the vector-ALU work, the global
+    // latency hidden as in the ring loop -- and SLOWER (25.7 vs 22.8 us at 8192 x 256 x 512): the plane stores, the second
+    // LDS round trip and the per-stage barrier behind the split cost more than the split they save.  Tool-only.
+    static constexpr bool LS = (PL_ & 16) != 0;
+    static constexpr int RAW_SZ = LS ? (WAVES_M_ * FM_ * 32 + WAVES_N_ * FN_ * 32) * KB_ : 0;   // floats of one raw stage
     // LDS floats of one stage: an fp32 tile is [T][KB] floats, a plane tile three [T][KB/2] images
     static constexpr int A_SZ = (PL & 5) ? 3 * (WAVES_M_ * FM_ * 32) * (KB_ / 2) : (WAVES_M_ * FM_ * 32) * KB_;
     static constexpr int B_SZ = (PL & 10) ? 3 * (WAVES_N_ * FN_ * 32) * (KB_ / 2) : (WAVES_N_ * FN_ * 32) * KB_;
@@ -571,6 +577,8 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     constexpr bool PRE = (PL & 3) != 0;                      // an operand arrives pre-split (pure LDS-DMA kernel)
     constexpr bool PSA = (PL & 4) != 0, PSB = (PL & 8) != 0;  // fp32 operand split when its stage is stored to LDS (register-staged kernel)
     constexpr bool PA = (PL & 5) != 0, PB = (PL & 10) != 0;   // the operand's LDS image is three plane images
+    constexpr bool LS = Cfg::LS;                               // ... split from a DMA-filled raw fp32 ring in LDS (below)
+    static_assert(!LS || (MODE == kNT && PSA && PSB && VEC && !GATHER && NB == 1), "split-from-LDS: NT products, both operands, 16-byte rows");
     static_assert(!PRE || (MODE == kNT && NB == 1 && VEC && Cfg::SPLIT), "plane operands: NT products of the split flavour");
     static_assert(!(PSA || PSB) || (!PRE && NB == 1 && Cfg::SPLIT), "split-at-store: split flavour, one B operand, no pre-split operand beside it");
     static_assert(!PSA || MODE == kNT || MODE == kNN, "split-at-store of A needs a contraction-contiguous A");
@@ -604,9 +612,9 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     KMajorStage<TM, KB, VEC, GATHER> ak;
     MMajorStage<TN, KBB, VEC, GATHER> bm;
     KMajorStage<TN, KB, VEC, GATHER> bk[NB];
-    if constexpr (A_MM) am.template init<PRE>(A, m0, d.M, t);
+    if constexpr (A_MM) am.template init<PRE || LS>(A, m0, d.M, t);
     else ak.init(A, m0, d.M, t);
-    if constexpr (B_MM) bm.template init<PRE>(B, n0, d.N, t);
+    if constexpr (B_MM) bm.template init<PRE || LS>(B, n0, d.N, t);
     else {
 #pragma unroll
         for (int b = 0; b < NB; ++b) bk[b].init(B, n0, d.N, t);
@@ -1023,7 +1031,64 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
     // no reason to wait on the vector-memory counter inside the MFMA phase.  Whatever remains -- the
     // ragged last stage of such a workgroup, or every stage of an edge tile / scalar-load / covariance
     // shift workgroup -- runs the register-staged loop behind it.
-    const bool dense_ok = PRE || (!(PSA || PSB) && nst > 0 && stage_dense(k_begin) && affine_all());   // split-at-store: every stage through registers
+    if constexpr (LS) {
+        // ---- split-from-LDS loop (TileCfg::PL bit 4).  The fp32 stage of BOTH operands arrives by LDS-DMA in a raw ring of
+        // two buffers behind the plane buffers (no VGPR round trip, the latency of the global loads stays hidden as in the
+        // ring loop); one pass per stage reads it back (4 ds_read_b128 per thread), splits it ONCE per workgroup and stores
+        // the three plane images the MFMA side reads -- the in-register split repeats that work in every wave that shares
+        // a fragment (two of the four waves of a 2 x 2 layout).  Per stage and wave: raw reads of stage st + 1, DMA issue
+        // of stage st + 2, the products of stage st from its planes, the split + plane stores of stage st + 1, one barrier.
+        // The launch guarantees K % KB == 0 and 16-byte rows; ragged row tiles read clamped rows (MMajorStage::init<true>).
+        constexpr int PERA = MMajorStage<TM, KA, VEC, GATHER>::PER, PERB = MMajorStage<TN, KBB, VEC, GATHER>::PER;
+        constexpr int RAW = Cfg::RAW_SZ;
+        float* const raw0 = lds + Cfg::NBUF * STAGE;
+        const int64_t nst_ls = (k_end - k_begin) / KB;
+        auto dma_raw = [&](int64_t k0, int rb) {
+            float* rbuf = raw0 + rb * RAW;
+            const unsigned l0 = ldsw + (unsigned)(Cfg::NBUF * STAGE + rb * RAW) * 4u;
+            if (pl_a_aff) am.glds_affine(am.tile_base(A, m0_ld, k0), l0);
+            else am.glds(k0, rbuf, t);
+            if (pl_b_aff) bm.glds_affine(bm.tile_base(B, n0, k0), l0 + (unsigned)(TM * KB) * 4u);
+            else bm.glds(k0, rbuf + TM * KB, t);
+        };
+        auto raw_to_regs = [&](int rb) {
+            const float* rbuf = raw0 + rb * RAW;
+#pragma unroll
+            for (int i = 0; i < PERA; ++i) am.r[i] = *reinterpret_cast<const float4*>(rbuf + (t + 256 * i) * 4);
+#pragma unroll
+            for (int i = 0; i < PERB; ++i) bm.r[i] = *reinterpret_cast<const float4*>(rbuf + TM * KB + (t + 256 * i) * 4);
+        };
+        auto split_to_planes = [&](float* pbuf) {
+            am.store_planes(pbuf, t);
+            bm.store_planes(pbuf + A_SZ, t);
+        };
+        if (nst_ls > 0) {
+            dma_raw(k_begin, 0);
+            if (nst_ls > 1) {
+                dma_raw(k_begin + KB, 1);
+                vm_wait<PERA + PERB>();   // stage 0 landed (stage 1 may still be in flight)
+            } else {
+                vm_wait<0>();
+            }
+            __syncthreads();
+            raw_to_regs(0);
+            split_to_planes(lds);
+            vm_wait<0>();                 // stage 1 landed
+            __syncthreads();              // planes of stage 0 published; raw buffer 0 read by everyone
+            for (int64_t st = 0; st < nst_ls; ++st) {
+                const int cur = (int)(st & 1);
+                if (st + 1 < nst_ls) raw_to_regs(cur ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (st + 2 < nst_ls) dma_raw(k_begin + (st + 2) * KB, cur);   // raw buffer `cur` was read one barrier ago
+                __builtin_amdgcn_sched_barrier(0);
+                if (m0 + wm < d.M) compute_stage(lds + cur * STAGE);
+                if (st + 1 < nst_ls) split_to_planes(lds + (cur ^ 1) * STAGE);   // that plane buffer was multiplied one barrier ago
+                vm_wait<0>();
+                __syncthreads();
+            }
+        }
+    }
+    const bool dense_ok = !LS && (PRE || (!(PSA || PSB) && nst > 0 && stage_dense(k_begin) && affine_all()));   // split-at-store: every stage through registers
     const int64_t nfull = dense_ok ? (k_end - k_begin) / KB : 0;
     if (nfull > 0) {
         const int64_t nst = nfull;   // stages of the ring loop
@@ -1224,7 +1289,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
         DCV_STAMP_RT(5);
     }
     const int64_t k_rem = k_begin + nfull * KB;
-    const int64_t nrem = PRE ? 0 : (k_end - k_rem + KB - 1) / KB;
+    const int64_t nrem = (PRE || LS) ? 0 : (k_end - k_rem + KB - 1) / KB;
     if (nrem > 0) {
         resolve_stage(k_rem);
         load_stage(k_rem);
@@ -1463,7 +1528,7 @@ __device__ __forceinline__ void gemm_block(const Operand& A, const Operand& B, i
 
 template <class Cfg, int NB>
 constexpr size_t gemm_lds_bytes() {
-    return (size_t)Cfg::NBUF * (Cfg::A_SZ + NB * Cfg::B_SZ) * sizeof(float);
+    return ((size_t)Cfg::NBUF * (Cfg::A_SZ + NB * Cfg::B_SZ) + 2 * (size_t)Cfg::RAW_SZ) * sizeof(float);
 }
 
 }  // namespace dcv

@@ -578,6 +578,19 @@ static CfgPick pick_cfg(int64_t M, int64_t N, int64_t K, int64_t k_chunk) {
     }
     return kPickBig;
 }
+// Split-from-LDS configurations (TileCfg::PL bit 4): NT products with 16-byte rows, no gathered rows and K a multiple of the
+// stage depth; returns 1 when the product does not qualify (the caller takes the in-register split).
+template <class Cfg, class Epi>
+static int launch_gemm_ls(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, const Epi& epi, hipStream_t s,
+                          int* tiles_m_out, const TailWs* tw) {
+    if (K % Cfg::KB != 0 || A.shift || B.shift) return 1;
+    GemmPlan pl;
+    int rc = prepare_gemm<kNT, Cfg, 1, Epi>(A, B, M, N, K, 0, epi, tiles_m_out, tw, &pl);
+    if (rc) return rc;
+    if (!pl.vec || pl.gather) return 1;
+    return launch_gemm_vec<kNT, Cfg, 1, true, false, Epi>(A, B, 0, pl.d, pl.splits, epi, s);
+}
+
 template <int MODE, bool S, class Epi>
 static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64_t N, int64_t K, int64_t k_chunk,
                             const Epi& epi, hipStream_t s, int* tiles_m_out, const TailWs* tw = nullptr) {
@@ -603,6 +616,15 @@ static int launch_gemm_mode(const Operand& A, const Operand& B, int64_t M, int64
             if constexpr (!Epi::kHead) {
                 if (pick == kPickQuarter) return launch_gemm_cfg<MODE, TileCfg<2, 2, 1, 1, 32, 2, true, PS>, 1, Epi>(A, B, 0, M, N, K, k_chunk, epi, s, tiles_m_out, tw);
             }
+        }
+    }
+#endif
+#ifdef DCV_PS_EXPERIMENT   // tools/planes_bench only (-DDCV_PS_EXPERIMENT, DCV_LS=1): bit-identical and measured SLOWER (25.7 vs 22.8 us at 8192 x 256 x 512)
+    if constexpr (S && MODE == kNT && !Epi::kHead) {
+        static const bool ls_on = [] { const char* e = getenv("DCV_LS"); return e && e[0] == '1'; }();
+        if (ls_on && pick == kPickQuarter) {
+            const int rc = launch_gemm_ls<TileCfg<2, 2, 1, 1, 32, 2, true, 28>, Epi>(A, B, M, N, K, epi, s, tiles_m_out, tw);
+            if (rc != 1) return rc;
         }
     }
 #endif

@@ -675,3 +675,57 @@ def test_native_rccl_communicator_world1():
         for w, w0 in zip(res[mode][1], res["single"][1]):
             np.testing.assert_allclose(w, w0, atol=2e-6)
     comm.close()
+
+
+_SWITCH_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from deep_cartograph_amd import hip
+rng = np.random.Generator(np.random.PCG64(5))
+model = sys.argv[1]
+if model == "deep_tica":
+    dims, acts = [96, 64, 32, 3], ["leaky_relu", "tanh", None]
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=2048, lag=7, tica_reg=1e-6, lr=1e-3)
+else:
+    dims, acts = [96, 48, 16, 2, 16, 48, 96], ["leaky_relu", "leaky_relu", None, "leaky_relu", "leaky_relu", None]
+    eng = hip.Mlp("ae", dims, acts, max_batch=2048, latent_layer=3, lr=1e-3)
+    eng.set_feature_range(np.ones(96, np.float32))
+torch.manual_seed(3)
+lins = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
+eng.set_linears([(l.weight.detach().numpy(), l.bias.detach().numpy()) for l in lins])
+X = torch.from_numpy(rng.standard_normal((12000, 96)).astype(np.float32).cumsum(0) * 0.02 + rng.standard_normal((12000, 96)).astype(np.float32)).cuda()
+eng.reset_log(64)
+for i in range(8):
+    eng.train_step(X, row0=i * 1000, batch=2048 if i % 2 else 1999)
+torch.cuda.synchronize()
+h = hashlib.sha256()
+for w, b in eng.get_linears():
+    h.update(np.ascontiguousarray(w).tobytes()); h.update(np.ascontiguousarray(b).tobytes())
+h.update(np.ascontiguousarray(eng.read_log()[:8, 0]).tobytes())
+print("HASH", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("model", ["deep_tica", "ae"])
+def test_launch_time_switches_leave_the_bits_alone(model, tmp_path):
+    """The speed switches of the library change how results are stored or summed up in the SAME order, never the results:
+    write-through epilogue stores (DCV_WT), the flat-grid gradient reduction (DCV_REDUCE_QUAD), the grouped weight /
+    input gradient launch (DCV_NO_PAIR).  Eight training steps in fresh processes (the switches are read once per
+    process), parameters and losses hashed."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "switch_run.py"
+    script.write_text(_SWITCH_SCRIPT.format(root=root))
+    hashes = {}
+    for name, env in (("default", {}), ("plain stores", {"DCV_WT": "0"}), ("round-2 reduction", {"DCV_REDUCE_QUAD": "0"}),
+                      ("two launches", {"DCV_NO_PAIR": "1"})):
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, str(script), model], env=e, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        hashes[name] = [l for l in out.stdout.splitlines() if l.startswith("HASH")][-1]
+    assert len(set(hashes.values())) == 1, hashes

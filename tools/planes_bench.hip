@@ -87,6 +87,22 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hc0.data(), C0, hc0.size() * 4, hipMemcpyDeviceToHost));
     report("in-register split (PL=0)", time_ms([&] { launch_gemm<kNT, EpiBiasAct>(a, b, M, N, K, 0, e0, s); }, it));
 
+    if (getenv("DCV_OCC_PROBE")) {   // the same flops as 64 x 64 tiles at 2, 4 and 8 workgroups per CU: rows doubled, contraction halved
+        for (int f = 1; f <= 4; f *= 2) {
+            const int64_t Mf = 8192 * f, Kf = 512 / f;
+            float *Af, *Cf;
+            CK(hipMalloc(&Af, (size_t)Mf * Kf * 4));
+            CK(hipMalloc(&Cf, (size_t)Mf * N * 4));
+            CK(hipMemcpy(Af, h.data(), (size_t)8192 * 512 * 4, hipMemcpyHostToDevice));
+            const Operand af = make_operand(Af, Kf, Kf), bf = make_operand(B, Kf, Kf);
+            EpiBiasAct ef{Cf, N, bias, act, true};
+            const double ms = time_ms([&] { launch_gemm_cfg<kNT, CfgQuarterT<true>, 1, EpiBiasAct>(af, bf, 0, Mf, N, Kf, 0, ef, s, nullptr, nullptr); }, it);
+            printf("occupancy probe: %lld x %lld x %lld, 64 x 64 tiles, %lld workgroups (%d per CU), %d stages each: %.1f us\n", (long long)Mf, (long long)N,
+                   (long long)Kf, (long long)(Mf / 64 * (N / 64)), (int)(Mf / 64 * (N / 64) / 256), (int)(Kf / 32), ms * 1e3);
+            CK(hipFree(Af));
+            CK(hipFree(Cf));
+        }
+    }
     {   // contraction-split tail tile (GemmDims::tail_split): only the rows of the ragged last tile may differ, by rounding
         TailWs tw;
         if (!alloc_tail_ws(&tw, 8)) { printf("tail workspace: allocation failed\n"); return 1; }

@@ -16,7 +16,8 @@ python tools/pmc_summary.py $OUT/stats $OUT/kernel_trace_summary.json > $OUT/ker
 rm -rf $OUT/stats
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $CMDLINE > $OUT/$name.out 2> $OUT/$name.err
+  # a pass that stalls inside the profiler (seen once: no kernel ever launched) must not take the whole call with it
+  timeout -k 10 ${PMC_PASS_TIMEOUT:-330} rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -- python3 $CMDLINE > $OUT/$name.out 2> $OUT/$name.err
   echo "$name exit $?"
   python tools/pmc_summary.py $OUT/$name $OUT/$name.summary.json > $OUT/$name.summary.txt 2>&1
   rm -rf $OUT/$name

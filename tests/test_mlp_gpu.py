@@ -56,6 +56,9 @@ def rel_err(a, b):
     # slope (1 vs 0.01) moves a gradient entry by 1e-4 of the largest one -- in the float32 oracle just as in either
     # arithmetic flavour of the engine (measured: FP32-input MFMA 3.8e-4, split 3e-7 on this very batch)
     ([512, 256, 128, 3, "tanh"], 8300, 10, 8192, False),
+    # 4096 pairs + lag = 4106 shared rows: the row-limited weight-gradient plan (mlp.hip: wgrad_plan) takes 16 contraction
+    # chunks of 257 rows -- chunk ends that are no stage multiple (the stage tail goes through registers), 64 x 64 tiles
+    ([512, 256, 128, 3, "tanh"], 4200, 10, 4096, False),
 ])
 def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather, mode):
     """One Deep-TICA step (statistics, loss, every gradient) against a FLOAT64 run of the autograd oracle on the same

@@ -204,8 +204,9 @@ class Fit:
                 traffic = entry.get("kernels", {}).get(name, {}).get("hbm_bytes_per_launch")
         return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel": kname, "rows_per_launch": R, "flop_per_launch": fl, "avg_ms": ms,
-                "timing_source": "HIP events recorded on the launch stream around that launch inside bench.py (dcv_mlp_profile_*), every "
-                                 "--profile-every-th timed step; rocprofv3 --kernel-trace reads ~4-5 us less per launch (profiles/)",
+                "timing_source": "HIP events on the launch stream stamped with that launch's own begin / end (hipExtLaunchKernel through "
+                                 "dcv_mlp_profile_*: the interval rocprofv3 --kernel-trace reports, profiles/), live inside bench.py, every "
+                                 "--profile-every-th timed step",
                 "all_kernels_ms": {k: v[1] for k, v in sorted(per.items())}, "note": note}
 
     def close(self):

@@ -35,6 +35,16 @@ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 constexpr int kWave = 64;  // gfx950 wavefront
 
+// Kernel-exact timing of ONE launch (dcv_mlp_profile_*): the caller parks a pair of events here, the block engine's launcher
+// hands them to hipExtLaunchKernel, which stamps them with the kernel's own begin / end (the interval rocprofv3 reports:
+// events recorded around a launch also bracket the command processor's work between launches, 3-4 us at the contract batch),
+// and clears the slot.  A slot nobody consumed (a launch that does not go through the block engine) is noticed by the
+// caller, which then falls back to recording its events around the launch.
+struct LaunchEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchEvents g_launch_ev;
+extern thread_local hipEvent_t g_launch_taken;   // start event of the pair the launcher consumed last
 // Number of CUs of the current device (cached).
 int num_cus();
 // arithmetic of the matrix products: false = FP32-input MFMA, true = FP32-accurate split products on the BF16

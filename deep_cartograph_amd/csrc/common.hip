@@ -22,6 +22,8 @@ int num_cus() {
     return cached;
 }
 
+thread_local LaunchEvents g_launch_ev;
+thread_local hipEvent_t g_launch_taken = nullptr;
 static int g_gemm_split = -1;   // -1: not decided yet (environment, else the default)
 bool gemm_split() {
     if (g_gemm_split < 0) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <type_traits>
 #include <stdlib.h>
+#include <hip/hip_ext.h>
 #include "gemm.h"
 
 namespace dcv {
@@ -414,7 +415,14 @@ static int launch_gemm_vec(const Operand& A, const Operand& B, int64_t lag2, con
         }
     }
     const int64_t blocks = d.tail_split > 0 ? (int64_t)(d.tiles_m - 1 + d.tail_split) * d.tiles_n : (int64_t)d.tiles_m * d.tiles_n;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
+    if (g_launch_ev.start != nullptr) {   // a profiled launch: the events carry the kernel's own begin / end (common.h)
+        const LaunchEvents ev = g_launch_ev;
+        g_launch_ev = LaunchEvents{};
+        g_launch_taken = ev.start;
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)splits), dim3(256), (uint32_t)lds, s, ev.start, ev.stop, 0u, A, B, lag2, d, epi);
+    } else {
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)splits), dim3(256), lds, s, A, B, lag2, d, epi);
+    }
     DCV_CHECK_LAUNCH();
     return DCV_OK;
 }

@@ -1263,10 +1263,24 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
 static inline bool prof_on(const dcv_mlp* m, int layer) {
     return m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap && (m->prof_level > 1 || layer == 0);
 }
+// which = 0: before the launch(es) of the class, 1: after.  The pair of events is offered to the block engine's launcher
+// (g_launch_ev, common.h), which stamps it with the kernel's own begin / end; when the launch in between did not take it
+// (the fused small-network step, a grouped launch), the events are recorded around the launch instead.
 static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStream_t s) {
     if (!prof_on(m, layer)) return;
     const size_t cls = (size_t)3 * layer + kind;
-    (void)hipEventRecord(m->prof_ev[(cls * m->prof_cap + m->prof_step) * 2 + which], s);
+    hipEvent_t* ev = &m->prof_ev[(cls * m->prof_cap + m->prof_step) * 2];
+    if (which == 0) {
+        (void)hipEventRecord(ev[0], s);
+        if (g_launch_ev.start == nullptr) g_launch_ev = LaunchEvents{ev[0], ev[1]};   // (one offer at a time: a grouped launch is bracketed by two classes)
+    } else {
+        if (g_launch_taken == ev[0]) {   // the launcher took the pair: both events carry the kernel's own times
+            g_launch_taken = nullptr;
+            return;
+        }
+        if (g_launch_ev.start == ev[0]) g_launch_ev = LaunchEvents{};
+        (void)hipEventRecord(ev[1], s);
+    }
 }
 
 // Deep-TICA batches.  Gathered batch (idx given): rows [0,B) are the x_t rows, rows [B,2B) the x_lag rows.

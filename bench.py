@@ -321,7 +321,7 @@ def main_c2(a):
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                 "traffic": None, "kernel": "snet_ae_kernel<32> (whole step fused: forward, loss, backward of a 32-row tile per workgroup, "
                                              "v_mfma_f32_16x16x4_f32, weights resident in LDS)",
-                "flop_per_launch": fl, "avg_ms": ms / cnt, "timing_source": "HIP events on the launch stream around the fused launch (bench.py)",
+                "flop_per_launch": fl, "avg_ms": ms / cnt, "timing_source": "HIP events stamped with the fused launch's own begin / end (hipExtLaunchKernel through dcv_mlp_profile_*), live inside bench.py",
                 "note": "algorithmic 6 * batch * sum(in*out) flop of one launch / its mean duration; the kernel is latency-bound at 4096 rows "
                         "(32 rows per workgroup, 128 workgroups): the fraction is reported for the record, not as a claim of MFMA saturation"}
     out = {"metric": "Autoencoder training frames/sec on 1Mx128 feature matrix (BASELINE.json configs[1]) at 1 GPU", "value": steps * bs / elapsed,

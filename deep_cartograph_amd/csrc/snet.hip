@@ -15,6 +15,7 @@
 // the network is far too small for the matrix rate to matter, and no operand splitting is needed.
 // A wave owns 16-row groups: TR = 32 -> waves (row group, column-tile parity); the k-slot permutation of gemm.h lets
 // one ds_read_b128 feed four MFMA steps (lane (n, q) holds k = k0 + 4q + s in step s, identically for A and B).
+#include <hip/hip_ext.h>
 #include "mlp_state.h"
 #include <new>
 
@@ -637,7 +638,14 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
             attr_state[slot] = e == hipSuccess ? 1 : -1;
         }
         if (attr_state[slot] < 0) return 1;
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), pl->lds_bytes, s, a);
+        if (g_launch_ev.start != nullptr) {   // a profiled launch: events stamped with the kernel's own begin / end (common.h)
+            const LaunchEvents ev = g_launch_ev;
+            g_launch_ev = LaunchEvents{};
+            g_launch_taken = ev.start;
+            hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), (uint32_t)pl->lds_bytes, s, ev.start, ev.stop, 0u, a);
+        } else {
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), pl->lds_bytes, s, a);
+        }
         DCV_CHECK_LAUNCH();
         return DCV_OK;
     };

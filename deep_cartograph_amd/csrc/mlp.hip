@@ -1386,6 +1386,8 @@ static void mlp_free(dcv_mlp* m) {
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->opt_aux); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
     for (auto& l : m->layers) { f(l.H); f(l.slab); f(l.bpart); f(l.mask); f(l.Y); f(l.rm); f(l.rv); f(l.bn_stat); f(l.bn_part); f(l.bn_gpart); f(l.bn_bpart); }
+    g_launch_ev = LaunchEvents{};   // no stale offer of events that are about to be destroyed
+    g_launch_taken = nullptr;
     for (hipEvent_t e : m->prof_ev) (void)hipEventDestroy(e);
     f(m->tail.ws); f(m->tail.cnt);
     for (int i = 0; i < 4; ++i) if (m->gexec[i]) (void)hipGraphExecDestroy(m->gexec[i]);
@@ -1900,6 +1902,7 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
 static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                         int32_t train, void* stream, int fuse_head = 0) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_forward: null argument");
+    g_launch_ev = LaunchEvents{};   // an offer left behind by a launch that failed half way
     m->head_done = false;
     m->fwd_train = train != 0;
     if (m->fwd_train) m->cur_step = m->drop_step++;
@@ -2022,6 +2025,7 @@ static OptArgs next_opt_args(dcv_mlp* m);
 static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                          int64_t global_batch, int32_t train, void* stream, bool fuse_opt = false) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_backward: null argument");
+    g_launch_ev = LaunchEvents{};
     if (m->last_batch != batch) {
         set_error("dcv_mlp_backward: batch=%d does not match the preceding forward (%d)", batch, m->last_batch);
         return DCV_ESTATE;

@@ -87,6 +87,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(hc0.data(), C0, hc0.size() * 4, hipMemcpyDeviceToHost));
     report("in-register split (PL=0)", time_ms([&] { launch_gemm<kNT, EpiBiasAct>(a, b, M, N, K, 0, e0, s); }, it));
 
+    if (getenv("DCV_LS_BIG")) {   // split-from-LDS (TileCfg::PL bit 4) on 128 x 128 tiles with 16-deep stages: 80 KB of LDS, two workgroups per CU
+        CK(hipMemset(C1, 0xff, (size_t)M * N * 4));
+        rc = launch_gemm_ls<TileCfg<2, 2, 2, 2, 16, 2, true, 28>, EpiBiasAct>(a, b, M, N, K, e1, s, nullptr, nullptr);
+        if (rc) { printf("LS big launch failed (%d): %s\n", rc, dcv_last_error()); return 1; }
+        check("split-from-LDS 128 x 128");
+        report("split-from-LDS 128 x 128, KB 16", time_ms([&] { launch_gemm_ls<TileCfg<2, 2, 2, 2, 16, 2, true, 28>, EpiBiasAct>(a, b, M, N, K, e1, s, nullptr, nullptr); }, it));
+        report("in-register 128 x 128, KB 32", time_ms([&] { launch_gemm_cfg<kNT, CfgBigT<true>, 1, EpiBiasAct>(a, b, 0, M, N, K, 0, e0, s, nullptr, nullptr); }, it));
+        report("in-register 128 x 128, KB 16", time_ms([&] { launch_gemm_cfg<kNT, TileCfg<2, 2, 2, 2, 16, 2, true>, 1, EpiBiasAct>(a, b, 0, M, N, K, 0, e0, s, nullptr, nullptr); }, it));
+    }
     if (getenv("DCV_OCC_PROBE")) {   // the same flops as 64 x 64 tiles at 2, 4 and 8 workgroups per CU: rows doubled, contraction halved
         for (int f = 1; f <= 4; f *= 2) {
             const int64_t Mf = 8192 * f, Kf = 512 / f;

@@ -108,6 +108,12 @@ int main(int argc, char** argv) {
             const double ms = time_ms([&] { launch_gemm_cfg<kNT, CfgQuarterT<true>, 1, EpiBiasAct>(af, bf, 0, Mf, N, Kf, 0, ef, s, nullptr, nullptr); }, it);
             printf("occupancy probe: %lld x %lld x %lld, 64 x 64 tiles, %lld workgroups (%d per CU), %d stages each: %.1f us\n", (long long)Mf, (long long)N,
                    (long long)Kf, (long long)(Mf / 64 * (N / 64)), (int)(Mf / 64 * (N / 64) / 256), (int)(Kf / 32), ms * 1e3);
+            const double msh = time_ms([&] { launch_gemm_cfg<kNT, CfgHalfMT<true>, 1, EpiBiasAct>(af, bf, 0, Mf, N, Kf, 0, ef, s, nullptr, nullptr); }, it);
+            printf("occupancy probe: %lld x %lld x %lld, 64 x 128 tiles, %lld workgroups, %d stages each: %.1f us\n", (long long)Mf, (long long)N, (long long)Kf,
+                   (long long)(Mf / 64 * (N / 128)), (int)(Kf / 32), msh * 1e3);
+            const double msb = time_ms([&] { launch_gemm_cfg<kNT, CfgBigT<true>, 1, EpiBiasAct>(af, bf, 0, Mf, N, Kf, 0, ef, s, nullptr, nullptr); }, it);
+            printf("occupancy probe: %lld x %lld x %lld, 128 x 128 tiles, %lld workgroups, %d stages each: %.1f us\n", (long long)Mf, (long long)N, (long long)Kf,
+                   (long long)(Mf / 128 * (N / 128)), (int)(Kf / 32), msb * 1e3);
             CK(hipFree(Af));
             CK(hipFree(Cf));
         }

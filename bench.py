@@ -44,7 +44,10 @@ def parse():
     p.add_argument("--lr", type=float, default=1e-3)
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
-    p.add_argument("--profile-every", type=int, default=8, help="HIP events around the layer-0 products on every n-th timed step")
+    p.add_argument("--profile-every", type=int, default=0,
+                   help="HIP events (stamped with the launch's own begin / end) on the layer-0 products of every n-th timed step; 0 (default) = "
+                        "every step when --steps <= 100, every 8th otherwise.  The first timed step -- the one right behind the barrier: "
+                        "idle clocks, cold L2 -- is never sampled")
     p.add_argument("--large-batch", type=int, default=524208,
                    help="second measurement ('large_batch'): 8 x (65536 - lag) pairs -- every rank's step covers whole 128-row "
                         "tiles at 1/2/4/8 GPUs when the rows of x_t and x_lag are shared; 0 disables")
@@ -59,7 +62,15 @@ def parse():
                    help="data-parallel steps through the library's own RCCL communicator (dcv_comm_*: forward, all-reduces, backward and "
                         "update inside one C call) instead of torch.distributed's; torch.distributed still provides the launcher's "
                         "rendezvous, the barriers and the unique-id broadcast")
-    p.add_argument("--config", choices=["c4", "c2"], default="c4",
+    p.add_argument("--shuffled-steps", type=int, default=200,
+                   help="third measurement ('shuffled'): the reference's DEFAULT loader -- random_split + a fresh permutation per epoch "
+                        "(yaml_schemas/train_colvars.py:55-56) -- at the headline batch: gathered two-half evaluation, no row sharing; 0 disables")
+    p.add_argument("--c2-steps", type=int, default=400,
+                   help="one GPU only: append the bounded BASELINE.json configs[1] run (autoencoder on 1M x 128, batch 4096) as block 'c2'; 0 disables")
+    p.add_argument("--ref-small-steps", type=int, default=300,
+                   help="one GPU only: append block 'ref_small' -- Deep-TICA on the reference's own network sizes (54-16-8-2 of its test "
+                        "configuration, [15, 15] of default_config.yml) at batch 128 and 4096; 0 disables")
+    p.add_argument("--config", choices=["c4", "c2", "ref_small"], default="c4",
                    help="c4 (default): the headline, Deep-TICA on 10M x 512; c2: BASELINE.json configs[1], autoencoder 128-64-32-2-32-64-128 on "
                         "1M x 128 at batch 4096 (its own metric line with roofline and cpu_baseline; one GPU)")
     return p.parse_args()
@@ -112,11 +123,12 @@ class Fit:
 
     PRIME = 30   # untimed priming steps in front of the W warm-up steps of every run()
 
-    def __init__(self, hip, dist, Xn, dims, acts, lag, global_batch, world, lr, linears, n_local, step_comm=None):
+    def __init__(self, hip, dist, Xn, dims, acts, lag, global_batch, world, lr, linears, n_local, step_comm=None, shuffled=False, seed=0):
         self.hip, self.dist, self.Xn, self.dims, self.lag = hip, dist, Xn, dims, lag
         self.step_comm = step_comm if step_comm is not None else dist   # what the data-parallel steps exchange through
         self.gb = global_batch
         self.lb = global_batch // world
+        self.shuffled = shuffled
         P_local = n_local - lag
         self.n_train = int(P_local * 0.8) // self.lb * self.lb
         self.steps_per_epoch = self.n_train // self.lb
@@ -125,9 +137,33 @@ class Fit:
         self.eng = hip.Mlp("deep_tica", dims, acts, max_batch=self.lb, lag=lag, tica_reg=1e-6, lr=lr)
         self.eng.set_linears(linears)
         self.sv, self.gv = self.eng.stats_view(), self.eng.grads_view()
+        if shuffled:
+            # the reference's default loader (yaml_schemas/train_colvars.py:55-56: shuffle True, random_split True; DictModule /
+            # DictLoader of mlcolvar): ONE random permutation of the pairs splits them into training / validation, the
+            # training pairs are re-permuted at every epoch start, a batch is a consecutive slice of that permutation.  A pair
+            # index p stands for (row p, row p + lag): the engine gathers both halves through the int64 index (RowMap).
+            self.gen = torch.Generator(device=Xn.device)
+            self.gen.manual_seed(1234 + seed)
+            perm = torch.randperm(P_local, generator=self.gen, device=Xn.device)
+            self.train_idx = perm[: self.n_train].contiguous()
+            self.val_idx = perm[self.n_train: self.n_train + self.val_steps * self.lb].contiguous()
+            self.epoch_idx = None
+
+    def _epoch_start(self):
+        self.epoch_idx = self.train_idx[torch.randperm(self.n_train, generator=self.gen, device=self.Xn.device)].contiguous()
 
     def train_step(self, i):
-        eng, r0 = self.eng, (i % self.steps_per_epoch) * self.lb
+        eng, j = self.eng, i % self.steps_per_epoch
+        if self.shuffled:
+            if j == 0 or self.epoch_idx is None:
+                self._epoch_start()
+            idx = self.epoch_idx[j * self.lb:(j + 1) * self.lb]
+            if self.dist is None:
+                eng.train_step(self.Xn, idx=idx)
+            else:
+                eng.data_parallel_step(self.Xn, self.step_comm, self.gb, idx=idx, train=True)
+            return
+        r0 = j * self.lb
         if self.dist is None:
             eng.train_step(self.Xn, row0=r0, batch=self.lb)
         else:   # statistics all-reduce, then the gradient all-reduce of the upper layers under the layer-0 weight gradient
@@ -136,6 +172,13 @@ class Fit:
     def validation_pass(self):
         eng = self.eng
         for j in range(self.val_steps):
+            if self.shuffled:
+                idx = self.val_idx[j * self.lb:(j + 1) * self.lb]
+                if self.dist is None:
+                    eng.eval_step(self.Xn, idx=idx)
+                else:
+                    eng.data_parallel_step(self.Xn, self.step_comm, self.gb, idx=idx, train=False)
+                continue
             r0 = self.n_train + j * self.lb
             if self.dist is None:
                 eng.eval_step(self.Xn, row0=r0, batch=self.lb)
@@ -146,6 +189,15 @@ class Fit:
         if self.dist is not None:
             self.dist.barrier()
         torch.cuda.synchronize()
+
+    @staticmethod
+    def sample_plan(steps, profile_every):
+        """(every, sampled step numbers): every timed step when the run is short (the driver's 20 steps gave THREE samples at
+        every 8th step in round 3, one of them the step right behind the barrier -- 29.8 us live against 22.8 us in every
+        rocprofv3 trace), every 8th in long runs; never step 0 (idle clocks, cold L2 behind the synchronisation)."""
+        every = profile_every if profile_every > 0 else (1 if steps <= 100 else 8)
+        picked = [i for i in range(steps) if i % every == 0 and (i > 0 or steps == 1)]
+        return every, picked
 
     def run(self, steps, warmup, profile_every, with_validation=True):
         """Times exactly `steps` optimiser steps between barriers; returns (seconds [max over ranks], per-kernel
@@ -158,21 +210,23 @@ class Fit:
         for i in range(warmup):
             self.train_step(i)
         self.barrier()
-        sampled = max(1, steps // max(1, profile_every)) + 1
-        if profile_every > 0:
-            eng.profile_begin(sampled, 1)
+        _, picked = self.sample_plan(steps, profile_every)
+        picked = set(picked)
+        self.samples = len(picked)
+        if picked:
+            eng.profile_begin(len(picked) + 1, 1)
         t0 = time.perf_counter()
         self.val_timed = 0
         for i in range(steps):
-            if profile_every > 1:
-                eng.profile_pause(i % profile_every != 0)
+            if picked:
+                eng.profile_pause(i not in picked)
             self.train_step(i)
             if with_validation and (i + 1) % self.steps_per_epoch == 0:
                 self.validation_pass()
                 self.val_timed += self.val_steps
         self.barrier()
         elapsed = time.perf_counter() - t0
-        prof = eng.profile_end() if profile_every > 0 else {}
+        prof = eng.profile_end() if picked else {}
         log = eng.read_log()
         if self.dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.Xn.device)
@@ -180,12 +234,43 @@ class Fit:
             elapsed = float(t.item())
         return elapsed, prof, log
 
+    def time_collectives(self, reps=40):
+        """Measured us per all-reduce of the two things a data-parallel step exchanges (HIP events around `reps` back-to-back
+        collectives on the step's stream, after a barrier; max over ranks): the 2d + 2d^2 float64 batch statistics and the
+        float32 gradient buffer."""
+        if self.dist is None:
+            return None
+        out = {}
+        comm = self.step_comm
+        for name, buf in (("statistics", self.sv), ("gradients", self.gv)):
+            def once():
+                if comm is self.dist:
+                    self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM)
+                else:
+                    comm.all_reduce(buf, "sum")
+            for _ in range(5):
+                once()
+            self.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                once()
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) * 1e3 / reps], dtype=torch.float64, device=self.Xn.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            out[name] = {"us_per_allreduce": float(t.item()), "bytes": int(buf.numel() * buf.element_size()), "dtype": str(buf.dtype).replace("torch.", "")}
+        out["note"] = (f"{reps} back-to-back all-reduces between HIP events on the launch stream, max over ranks; "
+                       "a step issues one of each (the gradient one in two pieces from 32768 rows per rank up)")
+        return out
+
     def roofline(self, prof, gemm_mode, traffic_table):
         """Roofline object of the slower layer-0 product (the dominant kernel of the step): algorithmic flop of one
         launch / its mean duration between HIP events on the launch stream, against the ceiling of the arithmetic."""
         if not prof:
             return None
-        R = self.lb + self.lag   # contiguous batches: the network runs once on the batch + lag rows both halves share
+        # contiguous batches: the network runs once on the batch + lag rows both halves share; gathered (shuffled) batches: 2 x batch rows
+        R = 2 * self.lb if self.shuffled else self.lb + self.lag
         per = {f"layer{l}.{k}": (2.0 * R * self.dims[l] * self.dims[l + 1], ms / cnt) for (l, k), (ms, cnt) in prof.items()}
         name, (fl, ms) = max(per.items(), key=lambda kv: kv[1][1])
         achieved = fl / (ms * 1e-3) / 1e12
@@ -205,8 +290,10 @@ class Fit:
         return {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                 "kernel": kname, "rows_per_launch": R, "flop_per_launch": fl, "avg_ms": ms,
                 "timing_source": "HIP events on the launch stream stamped with that launch's own begin / end (hipExtLaunchKernel through "
-                                 "dcv_mlp_profile_*: the interval rocprofv3 --kernel-trace reports, profiles/), live inside bench.py, every "
-                                 "--profile-every-th timed step",
+                                 "dcv_mlp_profile_*: the interval rocprofv3 --kernel-trace reports, profiles/), live inside bench.py: "
+                                 f"{getattr(self, 'samples', 0)} sampled timed steps (every step of a run of <= 100 steps, every 8th otherwise; never the "
+                                 "first one behind the barrier)",
+                "samples": getattr(self, "samples", 0),
                 "all_kernels_ms": {k: v[1] for k, v in sorted(per.items())}, "note": note}
 
     def close(self):
@@ -260,10 +347,11 @@ def cpu_baseline_ae(Xn_host, dims, acts_enc, acts_dec, latent, batch, lr, second
     return done * batch / dt, done, dt
 
 
-def main_c2(a):
+def run_c2(a, steps, warmup, cpu_seconds):
     """BASELINE.json configs[1]: autoencoder CV (2 hidden layers, dim 2) on 1M frames x 128 synthetic features, one MI355X.
     A step = one optimiser step over 4096 frames; the fit loop is the reference's (lengths [0.8, 0.2], sequential split,
-    validation pass at every epoch end inside the timed region)."""
+    validation pass at every epoch end inside the timed region).  Returns the metric object (its own value / roofline /
+    cpu_baseline)."""
     from deep_cartograph_amd import hip
     from deep_cartograph_amd.synth import synth_features
 
@@ -285,7 +373,6 @@ def main_c2(a):
     eng.set_feature_range(std.astype(np.float32))
     n_train = int(n * 0.8) // bs * bs
     spe, val_steps = n_train // bs, (n - n_train) // bs
-    steps = a.steps
 
     def train_step(i):
         eng.train_step(Xn, row0=(i % spe) * bs, batch=bs)
@@ -294,23 +381,26 @@ def main_c2(a):
         for j in range(val_steps):
             eng.eval_step(Xn, row0=n_train + j * bs, batch=bs)
 
-    eng.reset_log(2 * (steps + a.warmup + 64) + (steps // spe + 2) * (val_steps + 1))
-    for i in range(30 + a.warmup):
+    eng.reset_log(2 * (steps + warmup + 64) + (steps // spe + 2) * (val_steps + 1))
+    for i in range(30 + warmup):
         train_step(i)
     torch.cuda.synchronize()
-    sampled = max(1, steps // max(1, a.profile_every)) + 1
-    eng.profile_begin(sampled, 1)
+    _, picked = Fit.sample_plan(steps, a.profile_every)
+    picked = set(picked)
+    if picked:
+        eng.profile_begin(len(picked) + 1, 1)
     t0 = time.perf_counter()
     n_val = 0
     for i in range(steps):
-        eng.profile_pause(i % max(1, a.profile_every) != 0)
+        if picked:
+            eng.profile_pause(i not in picked)
         train_step(i)
         if (i + 1) % spe == 0:
             validation()
             n_val += val_steps
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    prof = eng.profile_end()
+    prof = eng.profile_end() if picked else {}
     log = eng.read_log()
     sw = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
     roof = None
@@ -319,41 +409,138 @@ def main_c2(a):
         fl = 6.0 * bs * sw
         ach = fl / (ms / cnt * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None, "kernel": "snet_ae_kernel<32> (whole step fused: forward, loss, backward of a 32-row tile per workgroup, "
+                "traffic": None, "kernel": "snet_ae_kernel (whole step fused: forward, loss, backward of a row tile per workgroup, "
                                              "v_mfma_f32_16x16x4_f32, weights resident in LDS)",
-                "flop_per_launch": fl, "avg_ms": ms / cnt, "timing_source": "HIP events stamped with the fused launch's own begin / end (hipExtLaunchKernel through dcv_mlp_profile_*), live inside bench.py",
-                "note": "algorithmic 6 * batch * sum(in*out) flop of one launch / its mean duration; the kernel is latency-bound at 4096 rows "
-                        "(32 rows per workgroup, 128 workgroups): the fraction is reported for the record, not as a claim of MFMA saturation"}
+                "flop_per_launch": fl, "avg_ms": ms / cnt, "samples": cnt,
+                "timing_source": "HIP events stamped with the fused launch's own begin / end (hipExtLaunchKernel through dcv_mlp_profile_*), live inside bench.py",
+                "note": "algorithmic 6 * batch * sum(in*out) flop of one launch / its mean duration; the kernel is latency-bound at 4096 rows: "
+                        "the fraction is reported for the record, not as a claim of MFMA saturation"}
     out = {"metric": "Autoencoder training frames/sec on 1Mx128 feature matrix (BASELINE.json configs[1]) at 1 GPU", "value": steps * bs / elapsed,
-           "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": a.warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+           "unit": "frames/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"Autoencoder fit (BASELINE.md C2), {n}x{F} f32 synthetic AR(1) features, MLP {'-'.join(map(str, dims))}, batch {bs}, "
                                   f"Adam lr {a.lr}, lengths [0.8,0.2], sequential split; {n_val} validation steps inside the timed region",
                       "frames": n, "features": F, "global_batch": bs, "steps_per_epoch": spe, "val_steps_per_epoch": val_steps,
                       "validation_steps_timed": n_val, "params": sw},
            "loss_first": float(log[0, 0]) if len(log) else None, "loss_last": float(log[-1, 0]) if len(log) else None, "roofline": roof}
-    if not a.no_cpu_baseline:
+    if cpu_seconds > 0:
         rows = min(n, 40 * bs)
-        v, done, dt = cpu_baseline_ae(Xn[:rows].cpu().numpy(), dims, acts[:latent], acts[latent:], latent, bs, a.lr, a.cpu_seconds, linears,
+        v, done, dt = cpu_baseline_ae(Xn[:rows].cpu().numpy(), dims, acts[:latent], acts[latent:], latent, bs, a.lr, cpu_seconds, linears,
                                       std.astype(np.float32))
         out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{done} optimiser steps of the torch-CPU oracle (same autoencoder, f32, batches of {bs}) on the first {rows} frames, {dt:.1f} s"}
     eng.close()
-    print(json.dumps(out))
+    del X, Xn
+    return out
+
+
+def run_ref_small(a, steps, cpu_seconds):
+    """Deep-TICA on the reference's OWN network sizes (cv_calculator.py:2569-2590): 54-16-8-2 (its test configuration,
+    tests/data/input/train_colvars + test_train_colvars.py) and F-15-15-2 (tools/train_colvars/default_config.yml:45-55 `layers:
+    [15, 15]`), at batch 128 (the test's clamp of 256) and 4096, with the reference's default loader (random split, fresh
+    permutation per epoch: gathered two-half batches).  One line per (network, batch): frames/s, us/step, the step's roofline
+    against the FP32-input MFMA peak (algorithmic 12 * sum(in*out) * batch flop per step), the torch-CPU oracle beside it."""
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd.synth import synth_features
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    n, F, lag = 400_000, 54, 10
+    X = synth_features(n, F, k_slow=2, shard=0, device=dev)
+    st = hip.finalize_stats(hip.col_stats_raw(X), n)
+    std = st["std"].copy()
+    std[np.abs(std) < 1e-8] = 1.0
+    hip.normalize(X, torch.from_numpy(st["mean"]).to(dev), torch.from_numpy(std).to(dev), out=X)
+    rows_out = []
+    for hidden in ([16, 8], [15, 15]):
+        dims = [F] + hidden + [2]
+        acts = ["leaky_relu"] * (len(dims) - 2) + [None]
+        linears = init_linears(dims, 43)
+        sw = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+        for bs in (128, 4096):
+            fit = Fit(hip, None, X, dims, acts, lag, bs, 1, a.lr, linears, n, shuffled=True)
+            elapsed, prof, log = fit.run(steps, 30, a.profile_every, with_validation=False)
+            fused = bool(fit.eng.lib.dcv_mlp_fused_small(fit.eng.h)) if hasattr(fit.eng.lib, "dcv_mlp_fused_small") else False
+            fl = 12.0 * sw * bs
+            us = elapsed / steps * 1e6
+            rec = {"network": "-".join(map(str, dims)), "batch": bs, "value": steps * bs / elapsed, "unit": "frames/s", "us_per_step": us,
+                   "steps": steps, "fused_small_network_path": fused, "loss_last": float(log[-1, 0]) if len(log) else None,
+                   "roofline": {"bound": "mfma", "achieved": fl / (us * 1e-6) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": fl / (us * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                "note": "whole step (every launch + gaps): algorithmic 12 * sum(in*out) * batch flop / step time; latency-bound by "
+                                        "construction at these sizes -- reported for the record"}}
+            fit.close()
+            if cpu_seconds > 0:
+                sample_rows = min(n, 40 * bs + lag)
+                v, done, dt = cpu_baseline(X[:sample_rows].cpu().numpy(), dims, acts, lag, bs, a.lr, cpu_seconds, linears)
+                rec["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                       "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, contiguous batches of {bs} pairs), {dt:.1f} s"}
+            rows_out.append(rec)
+    del X
+    return {"workload": f"Deep-TICA fit on the reference's own network sizes, {n}x{F} f32 synthetic AR(1) features, lag {lag}, Adam lr {a.lr}, "
+                        "random split + per-epoch permutation (the reference's default loader), training steps only",
+            "runs": rows_out}
+
+
+def self_launch(a):
+    """`python bench.py --gpus N` with no launcher environment: start N fresh child processes of this script, one rank per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set here), BEFORE anything in this process touches the GPU -- no os.exec*,
+    no re-launch of an initialised process.  Rank 0's standard output (the JSON line) is relayed; the exit code is non-zero
+    when any rank's is."""
+    import socket
+    import subprocess
+
+    n = a.gpus
+    ndev = torch.cuda.device_count()   # counting devices does not initialise the GPU on this image
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
+    if ndev < n and a.backend == "nccl":
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible and RCCL wants one device per rank "
+                         "(rehearse the multi-rank control flow on one GPU with --backend gloo)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for pr in procs:
+            pr.wait()
+            rc = rc or pr.returncode
+    finally:
+        for pr in procs:   # a rank that died leaves the others in a collective: end exactly the processes started here
+            if pr.poll() is None:
+                pr.kill()
+    sys.stdout.write(out0.decode() if out0 else "")
+    sys.stdout.flush()
+    if rc != 0:
+        raise SystemExit(rc if rc > 0 else 1)
+
+
+def main_c2(a):
+    print(json.dumps(run_c2(a, a.steps, a.warmup, 0.0 if a.no_cpu_baseline else a.cpu_seconds)))
 
 
 def main():
     a = parse()
-    if a.config == "c2":
+    if a.config != "c4":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
-        return main_c2(a)
+        if a.config == "c2":
+            return main_c2(a)
+        return print(json.dumps(run_ref_small(a, a.steps, 0.0 if a.no_cpu_baseline else min(a.cpu_seconds, 5.0))))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        return self_launch(a)   # before any GPU call in this process
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {a.gpus} inside a launcher environment of WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and there is no CPU path")
     torch.cuda.set_device(local_rank)
@@ -425,13 +612,33 @@ def main():
             if r:
                 other_res["roofline"] = {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_ms")}
     steps_per_epoch, val_steps = fit.steps_per_epoch, fit.val_steps
+    collectives = fit.time_collectives()
+    comm_world = None
+    if dist is not None:
+        comm_world = int(hip._lib.load().dcv_comm_world(step_comm.h)) if step_comm is not None else int(dist.get_world_size())
     fit.close()
+
+    # ---- the reference's default loader at the same batch: random split, a fresh permutation per epoch, gathered two-half batches
+    shuffled = None
+    if a.shuffled_steps > 0:
+        fs = Fit(hip, dist, Xn, dims, acts, lag, a.batch, world, a.lr, linears, n_local, step_comm, shuffled=True, seed=rank)
+        es, prof_s, log_s = fs.run(a.shuffled_steps, 20, a.profile_every, with_validation=False)
+        if rank == 0:
+            sw_ = sum(dims[i] * dims[i + 1] for i in range(len(dims) - 1))
+            shuffled = {"global_batch": a.batch, "value": a.shuffled_steps * a.batch / es, "unit": "frames/s", "ms_per_step": es / a.shuffled_steps * 1e3,
+                        "steps": a.shuffled_steps, "rows_per_launch": 2 * fs.lb, "flop_per_step": 12.0 * sw_ * fs.lb,
+                        "loss_last_train": float(log_s[-1, 0]) if len(log_s) else None,
+                        "roofline": fs.roofline(prof_s, a.gemm_mode, traffic_tables),
+                        "note": "reference default (yaml_schemas/train_colvars.py:55-56 shuffle / random_split True): x_t and x_lag rows are gathered "
+                                "through an int64 index, evaluated as two halves (2 x batch rows per product: twice the flops of the row-shared "
+                                "sequential headline), permutation drawn on the device at each epoch start inside the timed region; training steps only"}
+        fs.close()
 
     # ---- the same fit at a large global batch (MFMA-bound instead of launch / latency-bound)
     large = None
     if a.large_batch > 0 and a.large_batch % world == 0 and a.large_batch != a.batch and (n_local - lag) * 0.8 >= a.large_batch // world:
         fl_ = Fit(hip, dist, Xn, dims, acts, lag, a.large_batch, world, a.lr, linears, n_local, step_comm)
-        el, prof_l, _ = fl_.run(a.large_steps, 5, 1)
+        el, prof_l, _ = fl_.run(a.large_steps, 5, a.profile_every)
         if rank == 0:
             large = {"global_batch": a.large_batch, "value": a.large_steps * a.large_batch / el, "unit": "frames/s",
                      "ms_per_step": el / a.large_steps * 1e3, "steps": a.large_steps, "steps_per_epoch": fl_.steps_per_epoch,
@@ -467,6 +674,7 @@ def main():
                 "frames": a.frames, "features": F, "global_batch": a.batch, "parallelism": f"frame-shard dp{world}",
                 "collectives": (None if dist is None else ("libdcv RCCL communicator (dcv_comm_*)" if step_comm is not None else
                                                            f"torch.distributed {a.backend} through the all-reduce callback of dcv_mlp_dp_step")),
+                "communicator_world_size": comm_world, "collective_timing": collectives,
                 "steps_per_epoch": steps_per_epoch, "val_steps_per_epoch": val_steps, "validation_steps_timed": val_timed, "params": sw,
                 "gemm_mode": a.gemm_mode,
             },
@@ -478,6 +686,8 @@ def main():
             out["other_gemm_mode"] = other_res
         if large is not None:
             out["large_batch"] = large
+        if shuffled is not None:
+            out["shuffled"] = shuffled
         if not a.no_cpu_baseline and world == 1:
             sample_rows = min(n_local, 40 * a.batch + lag)
             Xh = Xn[:sample_rows].cpu().numpy()
@@ -487,7 +697,21 @@ def main():
                 "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, batches of {a.batch} pairs) on the first "
                           f"{sample_rows} frames, {dt:.1f} s",
             }
+        if world == 1 and dist is None:
+            # bounded runs of the other single-GPU configurations, carried by the same JSON line (the driver records one line)
+            del X, Xn
+            torch.cuda.empty_cache()
+            cpu_s = 0.0 if a.no_cpu_baseline else min(a.cpu_seconds, 8.0)
+            if a.c2_steps > 0:
+                c2 = run_c2(a, a.c2_steps, 50, cpu_s)
+                out["c2"] = {k: c2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "loss_first", "loss_last", "roofline") if k in c2}
+                if "cpu_baseline" in c2:
+                    out["c2"]["cpu_baseline"] = c2["cpu_baseline"]
+            if a.ref_small_steps > 0:
+                out["ref_small"] = run_ref_small(a, a.ref_small_steps, 0.0 if a.no_cpu_baseline else 3.0)
         print(json.dumps(out))
+    if step_comm is not None:
+        step_comm.close()   # the library's communicator goes before the process group that bootstrapped it
     if dist is not None:
         dist.destroy_process_group()
 

@@ -5,9 +5,10 @@
 // Python host broadcasts it with torch.distributed / a file / MPI).  librccl.so is opened at run time: libdcv.so
 // keeps loading on hosts without RCCL, where dcv_comm_create reports the reason.
 //
-// State of the evidence: built and exercised with world = 1 on the one-GPU box (tests/test_mlp_gpu.py); no multi-GPU
-// node has been available to the builder, so a multi-rank communicator has not executed -- bench.py therefore keeps
-// torch.distributed (the same RCCL underneath) as the default transport and takes this path with --native-rccl.
+// EXPERIMENTAL (include/dcv.h says so too).  State of the evidence: built and exercised with world = 1 on the one-GPU box
+// (tests/test_mlp_gpu.py); no multi-GPU node has been available to the builder, so a multi-rank communicator has not
+// executed -- bench.py therefore keeps torch.distributed (the same RCCL underneath) as the default transport and takes
+// this path with --native-rccl.
 #include "common.h"
 #include <dlfcn.h>
 #include <string.h>
@@ -31,9 +32,18 @@ RcclApi* rccl() {
     static bool tried = false;
     if (tried) return &api;
     tried = true;
-    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    // A process that already carries an RCCL -- torch bundles one and loads it with `import torch` -- must not get a second
+    // copy beside it (two RCCLs in one process each keep their own bootstrap threads and device state): first ask for the
+    // copy that is ALREADY mapped (RTLD_NOLOAD), only then load one.
+    for (const char* name : {"librccl.so.1", "librccl.so"}) {
+        api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (api.lib) break;
+    }
+    if (!api.lib) {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
     }
     if (!api.lib) {
         snprintf(api.why, sizeof(api.why), "librccl.so not found (%s)", dlerror());

@@ -490,6 +490,114 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_kernel(const double* 
     }
 }
 
+// ONE pass over the points for all centroids of a chunk (D <= 4 coordinates: the CV spaces of the pipeline): a thread keeps
+// the running minimum (distance, row) of up to KC centroids in registers and streams its points once, four in flight.  The
+// per-centroid form above re-reads every point k times (k = 6, 20M x 4: 3.84 GB moved for 0.64 GB of points, 597 us);
+// centroids beyond KC take further chunks on grid.y.  Same arithmetic (np_norm), same order per thread (increasing row,
+// strict '<'), same lexicographic (distance, row) combination: bit-identical rows.
+constexpr int kNearKC = 8;
+template <int D>
+__global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const double* __restrict__ P, int64_t n, const double* __restrict__ centers,
+                                                                        int k, double* __restrict__ pdist, int64_t* __restrict__ prow) {
+    constexpr int KC = kNearKC, U = 4;
+    __shared__ double s_c[KC][D];
+    __shared__ double s_d[4][KC];
+    __shared__ int64_t s_i[4][KC];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int j0 = blockIdx.y * KC;
+    const int kc = k - j0 < KC ? k - j0 : KC;
+    if (t < KC * D) {
+        const int j = t / D, q = t - j * D;
+        s_c[j][q] = j < kc ? centers[(int64_t)(j0 + j) * D + q] : 0.0;
+    }
+    __syncthreads();
+    double best[KC];
+    int64_t besti[KC];
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        best[j] = INFINITY;
+        besti[j] = INT64_MAX;
+    }
+    const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t begin = (int64_t)blockIdx.x * per_block;
+    const int64_t end = begin + per_block < n ? begin + per_block : n;
+    for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)U * kKmThreads) {
+        double x[U][D];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kKmThreads;
+            const double* p = P + (i < end ? i : i0) * D;
+            if constexpr (D % 2 == 0) {
+#pragma unroll
+                for (int q = 0; q < D; q += 2) {
+                    const double2 v = *reinterpret_cast<const double2*>(p + q);
+                    x[u][q] = v.x;
+                    x[u][q + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < D; ++q) x[u][q] = p[q];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + (int64_t)u * kKmThreads;
+            if (i >= end) break;
+#pragma unroll
+            for (int j = 0; j < KC; ++j) {
+                if (j < kc) {
+                    // np_norm for D < 8: sequentially added, separately rounded squares
+                    double res = 0.0;
+#pragma unroll
+                    for (int q = 0; q < D; ++q) {
+                        const double df = x[u][q] - s_c[j][q];
+                        res = __dadd_rn(res, __dmul_rn(df, df));
+                    }
+                    const double v = sqrt(res);
+                    if (v < best[j]) {   // increasing i: strict '<' keeps the first index
+                        best[j] = v;
+                        besti[j] = i;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        double b = best[j];
+        int64_t bi = besti[j];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double v2 = __shfl_down(b, off, 64);
+            const int64_t i2 = __shfl_down(bi, off, 64);
+            if (v2 < b || (v2 == b && i2 < bi)) {
+                b = v2;
+                bi = i2;
+            }
+        }
+        if (lane == 0) {
+            s_d[wave][j] = b;
+            s_i[wave][j] = bi;
+        }
+    }
+    __syncthreads();
+    if (t < kc) {
+        double b = s_d[0][t];
+        int64_t bi = s_i[0][t];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const double v2 = s_d[w][t];
+            const int64_t i2 = s_i[w][t];
+            if (v2 < b || (v2 == b && i2 < bi)) {
+                b = v2;
+                bi = i2;
+            }
+        }
+        pdist[(int64_t)(j0 + t) * gridDim.x + blockIdx.x] = b;
+        prow[(int64_t)(j0 + t) * gridDim.x + blockIdx.x] = bi;
+    }
+}
+
 // One wave per centroid: the lanes take the block partials b = lane, lane + 64, ... with four loads in flight each, then
 // a shuffle tree keeps the lexicographic minimum (distance, row) -- the same answer as a serial walk in block order (ties go
 // to the smaller row).  (One THREAD per centroid walked ~512 partials with dependent loads: 167 us for a 6-centroid final.)
@@ -628,7 +736,18 @@ extern "C" int dcv_nearest_rows(const double* P_d, int64_t n, int32_t d, const d
     const int nb = km_blocks(n);
     double* pdist = static_cast<double*>(ws_d);
     int64_t* prow = reinterpret_cast<int64_t*>(pdist + (size_t)kKmMaxBlocks * k);
-    hipLaunchKernelGGL(nearest_rows_kernel, dim3(nb, k), dim3(kKmThreads), 0, s, P_d, n, d, centers_d, pdist, prow);
+    static const bool multi_off = [] { const char* e = getenv("DCV_NEAREST_PER_CENTROID"); return e && e[0] == '1'; }();
+    const dim3 gm(nb, (unsigned)cdiv(k, kNearKC));
+    if (d <= 4 && !multi_off) {   // one pass over the points per chunk of kNearKC centroids
+        switch (d) {
+            case 1: hipLaunchKernelGGL(nearest_rows_multi_kernel<1>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+            case 2: hipLaunchKernelGGL(nearest_rows_multi_kernel<2>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+            case 3: hipLaunchKernelGGL(nearest_rows_multi_kernel<3>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+            default: hipLaunchKernelGGL(nearest_rows_multi_kernel<4>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+        }
+    } else {
+        hipLaunchKernelGGL(nearest_rows_kernel, dim3(nb, k), dim3(kKmThreads), 0, s, P_d, n, d, centers_d, pdist, prow);
+    }
     DCV_CHECK_LAUNCH();
     hipLaunchKernelGGL(nearest_rows_final, dim3((unsigned)k), dim3(64), 0, s, pdist, prow, nb, k, row_offset, dist_d, rows_d);
     DCV_CHECK_LAUNCH();

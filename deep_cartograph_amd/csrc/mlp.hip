@@ -1418,12 +1418,11 @@ static int reset_opt_state(dcv_mlp* m, hipStream_t s) {
         hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, m->adam_v, m->n_params, (float)m->desc.initial_accumulator_value);
         DCV_CHECK_LAUNCH();
     }
-    if (m->desc.optimizer == DCV_OPT_RPROP) {   // step_size starts at lr
-        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, m->adam_v, m->n_params, (float)m->desc.lr);
-        DCV_CHECK_LAUNCH();
-    }
+    // Rprop's step_size and ASGD's eta are created by torch inside the FIRST optimizer.step(), from the learning rate the
+    // group holds at that moment -- after a scheduler's constructor (OneCycleLR, LinearLR, a warm-up LambdaLR) has already
+    // rescaled it: seeded in first_step_state(), right before the first update, from m->lr
     m->nadam_mu_product = 1.0;
-    m->asgd_eta = (double)(float)m->desc.lr;
+    m->asgd_eta = (double)(float)m->lr;
     m->adam_t = 0;
     m->drop_step = 0;
     return DCV_OK;
@@ -1859,7 +1858,24 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
         (void)hipGetLastError();
         return body();
     }
-    const int64_t adam_t0 = m->adam_t, drop0 = m->drop_step;   // the host state a replay of body() must not advance twice
+    // the host state a replay of body() must not advance twice: step counters, NAdam's mu_product, ASGD's eta, the
+    // batch counts of the normalisations (all advanced inside body(): next_opt_args, bn_forward)
+    struct HostStep {
+        int64_t adam_t, drop_step, cur_step;
+        double mu_product, eta;
+        int64_t bn_batches[DCV_MAX_LAYERS];
+    };
+    auto snap = [&]() {
+        HostStep h{m->adam_t, m->drop_step, m->cur_step, m->nadam_mu_product, m->asgd_eta, {}};
+        for (int l = 0; l < m->L; ++l) h.bn_batches[l] = m->layers[l].bn_batches;
+        return h;
+    };
+    auto restore = [&](const HostStep& h) {
+        m->adam_t = h.adam_t; m->drop_step = h.drop_step; m->cur_step = h.cur_step;
+        m->nadam_mu_product = h.mu_product; m->asgd_eta = h.eta;
+        for (int l = 0; l < m->L; ++l) m->layers[l].bn_batches = h.bn_batches[l];
+    };
+    const HostStep h0 = snap();
     const int rc = body();
     hipGraph_t g = nullptr;
     const hipError_t ec = hipStreamEndCapture(s, &g);
@@ -1868,8 +1884,7 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
         (void)hipGetLastError();
         if (rc != DCV_OK) return rc;
         m->gwarm[slot] = false;   // capture failed: run this call (and relearn) without it
-        m->adam_t = adam_t0;
-        m->drop_step = drop0;
+        restore(h0);
         return body();
     }
     if (m->gexec[slot]) {
@@ -1888,8 +1903,7 @@ static int run_graphed(dcv_mlp* m, int slot, hipStream_t s, F&& body) {
     (void)hipGraphDestroy(g);
     if (!m->gexec[slot]) {   // nothing was launched yet: replay as plain launches and stop trying on this slot
         m->graph_off = true;
-        m->adam_t = adam_t0;
-        m->drop_step = drop0;
+        restore(h0);
         return body();
     }
     DCV_CHECK_HIP(hipGraphLaunch(m->gexec[slot], s));
@@ -2022,6 +2036,16 @@ static int launch_reduce(dcv_mlp* m, const ReduceArgs& ra_all, int l0, int l1, b
 }
 
 static OptArgs next_opt_args(dcv_mlp* m);
+// state that torch.optim creates lazily in its first step(): called (with the stream of the update) before next_opt_args
+static int first_step_state(dcv_mlp* m, hipStream_t s) {
+    if (m->adam_t != 0) return DCV_OK;
+    if (m->desc.optimizer == DCV_OPT_RPROP) {   // step_size = full_like(grad, lr)
+        hipLaunchKernelGGL(fill_kernel, dim3(256), dim3(256), 0, s, m->adam_v, m->n_params, (float)m->lr);
+        DCV_CHECK_LAUNCH();
+    }
+    if (m->desc.optimizer == DCV_OPT_ASGD) m->asgd_eta = (double)(float)m->lr;   // eta = as_tensor(lr)
+    return DCV_OK;
+}
 static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                          int64_t global_batch, int32_t train, void* stream, bool fuse_opt = false) {
     DCV_REQUIRE(m && Xn_d, "dcv_mlp_backward: null argument");
@@ -2220,7 +2244,11 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         dz_nxt = tmp;
     }
     OptArgs oa{};
-    if (fuse_opt) oa = next_opt_args(m);
+    if (fuse_opt) {
+        const int rcf = first_step_state(m, s);
+        if (rcf) return rcf;
+        oa = next_opt_args(m);
+    }
     int rc2 = launch_reduce(m, ra, 0, upper_done ? 1 : L, fuse_opt, oa, s);   // layer 0 only when the upper layers went out early
     if (rc2) return rc2;
     if (m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
@@ -2381,6 +2409,8 @@ static OptArgs next_opt_args(dcv_mlp* m) {
 static int apply_impl(dcv_mlp* m, void* stream) {
     DCV_REQUIRE(m, "dcv_mlp_apply: null");
     hipStream_t s = as_stream(stream);
+    const int rcf = first_step_state(m, s);
+    if (rcf) return rcf;
     const OptArgs a = next_opt_args(m);
     int64_t blocks = cdiv(m->n_params, 256);
     if (blocks > 1024) blocks = 1024;
@@ -2424,6 +2454,8 @@ static int snet_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* i
         rd.splits = v.splits[l];
         rd.bblocks = v.bblocks[l];
     }
+    const int rcf = first_step_state(m, s);
+    if (rcf) return rcf;
     return launch_reduce(m, ra, 0, m->L, true, next_opt_args(m), s);
 }
 
@@ -2490,6 +2522,21 @@ void dp_upper_cb(void* p) {
 extern "C" int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                                int64_t global_batch, int32_t train, int32_t overlap, dcv_allreduce_fn fn, void* user, void* stream) {
     DCV_REQUIRE(m && fn, "dcv_mlp_dp_step: null argument");
+    // Batch normalisation normalises with the rows of ONE forward call: in a frame-sharded step that would be each rank's
+    // local rows, the running statistics would drift apart between the ranks, and N ranks would no longer equal one process
+    // on the union batch (which every other part of this step guarantees).  Refused rather than silently different.
+    if (m->any_bn && global_batch != batch) {
+        set_error("dcv_mlp_dp_step: batch normalisation is not implemented for data-parallel fits (global batch %lld != local batch %d: "
+                  "the normalisation would use each rank's local rows only); fit on one GPU or drop `batchnorm`", (long long)global_batch, batch);
+        return DCV_EINVAL;
+    }
+    // whatever fails from here on, a reduction started with DCV_DP_UPPER_START must be joined before the caller gets the
+    // gradient buffer back: every exit below goes through fail()
+    bool started = false;
+    auto fail = [&](int rc) {
+        if (started) (void)fn(user, nullptr, 0, DCV_DTYPE_F32, DCV_DP_WAIT);
+        return rc;
+    };
     int rc = forward_impl(m, Xn_d, ld, idx_d, row0, batch, train, stream, 0);
     if (rc) return rc;
     if (fn(user, m->stats, m->stats_len, DCV_DTYPE_F64, DCV_DP_STATS) != 0) {
@@ -2505,13 +2552,18 @@ extern "C" int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const 
         void* keep_user = m->upper_cb_user;
         m->upper_cb = dp_upper_cb;
         m->upper_cb_user = &t;
+        started = true;   // (the trampoline may have started the exchange even when the backward fails behind it)
         rc = backward_impl(m, Xn_d, ld, idx_d, row0, batch, global_batch, 1, stream);
         m->upper_cb = keep_cb;
         m->upper_cb_user = keep_user;
-        if (rc) return rc;
-        if (t.rc != 0 || fn(user, m->grads, m->layers[1].w_off, DCV_DTYPE_F32, DCV_DP_GRADS) != 0 ||
-            fn(user, nullptr, 0, DCV_DTYPE_F32, DCV_DP_WAIT) != 0) {
+        if (rc) return fail(rc);
+        if (t.rc != 0 || fn(user, m->grads, m->layers[1].w_off, DCV_DTYPE_F32, DCV_DP_GRADS) != 0) {
             set_error("dcv_mlp_dp_step: the all-reduce callback failed (gradients)");
+            return fail(DCV_ECALLBACK);
+        }
+        started = false;
+        if (fn(user, nullptr, 0, DCV_DTYPE_F32, DCV_DP_WAIT) != 0) {
+            set_error("dcv_mlp_dp_step: the all-reduce callback failed (join)");
             return DCV_ECALLBACK;
         }
     } else {

@@ -996,6 +996,11 @@ class NonLinear(CVCalculator):
                               **self._engine_optimizer_kwargs(opt_name, opt_kw))
         self.engine.set_linears(linears)
         self.engine.set_rank(self.comm.rank)   # data-parallel ranks hold the same seed: independent dropout masks per rank
+        if self.comm.world > 1 and any(getattr(self, "_bn_plan", None) or []):
+            # each rank would normalise with its local rows and keep its own running statistics: no longer the reference's
+            # single-process fit (dcv_mlp_dp_step refuses it too) -- say so before the first step
+            raise ValueError("batchnorm / last_layer_batchnorm are not supported in a frame-sharded (multi-GPU) fit: run this CV on one GPU "
+                             "or drop the option")
         if self.model_kind == "ae":
             self.engine.set_feature_range(self.features_norm_range)
         self._stats_view = self.engine.stats_view()

@@ -247,7 +247,11 @@ int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void* user), void* u
  * part), and -- with overlap != 0 and more than one layer -- DCV_DP_UPPER_START for the gradients of layers 1.., handed
  * over BEFORE the layer-0 weight gradient is enqueued: that exchange may complete asynchronously under it and is
  * awaited by the closing call fn(user, NULL, 0, DCV_DTYPE_F32, DCV_DP_WAIT).  fn returns 0, or nonzero to abort the step
- * (dcv_mlp_dp_step then returns DCV_ECALLBACK).  train = 0: evaluation step (statistics exchanged, loss logged).
+ * (dcv_mlp_dp_step then returns DCV_ECALLBACK, after a DCV_DP_WAIT call that joins an exchange already started with
+ * DCV_DP_UPPER_START).  train = 0: evaluation step (statistics exchanged, loss logged).
+ * Batch normalisation (dcv_mlp_desc.batchnorm) is REFUSED when global_batch != batch (DCV_EINVAL): it would normalise
+ * with each rank's local rows and let the running statistics of the ranks drift apart, so N ranks would no longer equal
+ * one process on the union batch.
  * Replaces, on the reference side, lightning's DDP hooks around cv_calculator.py:1515-1524 (the reference itself is
  * single-process). */
 #define DCV_DTYPE_F32 0
@@ -259,7 +263,9 @@ int dcv_mlp_set_upper_grads_callback(dcv_mlp* m, void (*fn)(void* user), void* u
 typedef int (*dcv_allreduce_fn)(void* user, void* buf_d, int64_t count, int32_t dtype, int32_t phase);
 int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                     int64_t global_batch, int32_t train, int32_t overlap, dcv_allreduce_fn fn, void* user, void* stream);
-/* ---- RCCL communicator (one process per GPU; RCCL over xGMI inside a node).  The collectives of a frame-sharded fit issued
+/* ---- RCCL communicator (one process per GPU; RCCL over xGMI inside a node).  EXPERIMENTAL: executed with one rank only
+ * (no multi-GPU node has been available to the builder); the default transport of the Python host stays torch.distributed.
+ * The collectives of a frame-sharded fit issued
  * by the library itself, in stream order with its kernels.  dcv_comm_unique_id: rank 0 creates the 128-byte id and the
  * caller's bootstrap hands it to every rank; dcv_comm_create: collective over all ranks (ncclCommInitRank on the current
  * device).  dcv_comm_allreduce: in place, op 0 = SUM, 1 = MIN, 2 = MAX, dtype DCV_DTYPE_*, enqueued on `stream`.

@@ -41,3 +41,42 @@ def test_bench_world2_control_flow():
     assert line["roofline"] is not None and line["roofline"]["rows_per_launch"] == 2048 + 10
     assert line["loss_first"] is not None and -4.0 <= line["loss_last_train"] <= 0.0   # -sum(eig^2) of a d = 4 TICA
     assert "cpu_baseline" not in line
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with NO launcher environment: the script itself starts one fresh child
+    process per rank before it touches the GPU, relays rank 0's JSON line and exits 0.  Two ranks share the one GPU over
+    gloo; the line carries the communicator's world size, the measured all-reduce times, the large-batch and shuffled
+    blocks of the N > 1 path."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--frames", "600000", "--batch", "4096",
+            "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--large-batch", "65516", "--large-steps", "3", "--other-mode-steps", "0",
+            "--shuffled-steps", "5"]
+    p = subprocess.run(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["scaling"] == "strong"
+    cfg = line["config"]
+    assert cfg["parallelism"] == "frame-shard dp2" and cfg["communicator_world_size"] == 2
+    ct = cfg["collective_timing"]
+    assert ct["statistics"]["bytes"] == 8 * (2 * 4 + 2 * 16) and ct["statistics"]["us_per_allreduce"] > 0
+    assert ct["gradients"]["bytes"] == 4 * cfg["params"] and ct["gradients"]["us_per_allreduce"] > 0
+    # every step after the first one behind the barrier is sampled
+    assert line["roofline"]["samples"] == 5 and line["roofline"]["rows_per_launch"] == 2048 + 10
+    assert line["large_batch"]["global_batch"] == 65516 and line["large_batch"]["value"] > 0
+    assert line["shuffled"]["rows_per_launch"] == 2 * 2048 and line["shuffled"]["value"] > 0
+    assert "c2" not in line and "ref_small" not in line      # single-GPU blocks
+
+
+def test_bench_refuses_more_rccl_ranks_than_gpus():
+    """RCCL wants one device per rank: with fewer GPUs than ranks the self-launcher says so instead of hanging in init."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "one device per rank" in p.stderr

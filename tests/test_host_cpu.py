@@ -364,3 +364,20 @@ def test_layer_options_carry_batchnorm():
     act, drop, bn = NonLinear._layer_options({"layers": [8, 4], "activation": ["tanh", "relu"], "batchnorm": [True, False], "dropout": [0.1, None],
                                               "last_layer_batchnorm": True, "last_layer_activation": None}, 2)
     assert act == ["tanh", "relu", None] and drop == [0.1, 0.0, 0.0] and bn == [True, False, True]
+
+
+def test_bench_without_a_gpu_says_so_before_it_spawns_ranks():
+    """`bench.py --gpus 2` with no launcher environment on a box without a GPU: the self-launcher counts the devices
+    (torch.cuda.device_count() does not initialise anything) and stops with the message -- it does not start ranks
+    that would each fail on their own."""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, cwd=root, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=300)
+    assert p.returncode != 0 and "needs an MI355X" in p.stderr and p.stdout.strip() == ""

@@ -243,6 +243,28 @@ def test_nearest_rows_wide_d():
         np.testing.assert_array_equal(rows.cpu().numpy(), oc.find_centroid_rows(P, C))
 
 
+@pytest.mark.parametrize("d,k", [(1, 3), (2, 6), (3, 11), (4, 6), (4, 17)])
+def test_nearest_rows_one_pass_narrow_d(d, k):
+    """d <= 4: ONE pass over the points for every chunk of 8 centroids (nearest_rows_multi_kernel).  Rows bit-exact against
+    np.linalg.norm / argmin incl. exact ties (duplicated points: the first index wins) and centroids that ARE points; the
+    per-centroid kernel (DCV_NEAREST_PER_CENTROID=1 in a fresh process would select it) is covered by the wide-d test."""
+    from deep_cartograph_amd import hip
+
+    rng = np.random.Generator(np.random.PCG64(100 + 10 * d + k))
+    P = np.round(rng.uniform(-1, 1, (150_001, d)), 4)      # %.4f CSV values, as the pipeline hands them over
+    P[70_000:70_050] = P[10_000:10_050]                   # exact duplicates: ties in every distance
+    C = np.round(rng.uniform(-1, 1, (k, d)), 3)
+    C[0] = P[70_010]                                       # distance 0, reached at two rows: row 10 010 must win
+    dist, rows = hip.nearest_rows(dev(P), dev(C))
+    ref = oc.find_centroid_rows(P, C)
+    np.testing.assert_array_equal(rows.cpu().numpy(), ref)
+    assert rows[0].item() == 10_010
+    np.testing.assert_array_equal(dist.cpu().numpy(), np.linalg.norm(P[ref] - C, axis=1))
+    # a row offset (frame-sharded callers) shifts the reported rows only
+    _, rows_o = hip.nearest_rows(dev(P), dev(C), row_offset=1_000_000)
+    np.testing.assert_array_equal(rows_o.cpu().numpy(), ref + 1_000_000)
+
+
 @pytest.mark.parametrize("d,bins,blocks", [(1, 150, 1), (2, 100, 1), (2, 64, 4), (1, 5000, 1)])
 def test_fes_binned_kde_matches_oracle(d, bins, blocks):
     """f4, FES half: dcv_linear_binning + statistics.compute_fes against the NumPy restatement of the same binned KDE

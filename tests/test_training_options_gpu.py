@@ -387,6 +387,78 @@ def test_optimizers_follow_torch(name, kwargs):
     eng.close()
 
 
+@pytest.mark.parametrize("name,kwargs", [
+    ("Rprop", dict(lr=1e-3, etas=(0.5, 1.2), step_sizes=(1e-6, 1e-2))),
+    ("ASGD", dict(lr=0.02, lambd=1e-3, alpha=0.75)),
+])
+def test_lazy_optimizer_state_sees_the_schedulers_lr(name, kwargs):
+    """torch creates Rprop's step_size and ASGD's eta inside the FIRST optimizer.step(), from the learning rate
+    the group holds then -- after a scheduler's constructor has rescaled it (OneCycleLR starts at max_lr / 25).  The
+    engine seeds them right before its first update from the lr set through dcv_mlp_set_lr, not from the lr of creation."""
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd.cv_calculator import NonLinear, _OPTIMIZERS
+
+    F, batch, steps = 24, 512, 10
+    enc, dec = [F, 12, 2], [2, 12, F]
+    acts = ["tanh", None, "tanh", None]
+    X = ar_features(1600, F, 29)
+    Xn, m, r = normalized(X)
+    torch.manual_seed(37)
+    ref = onn.AEModel(enc, acts[:2], None, dec, acts[2:], None, m, r)
+    lins = linears_of(ref.encoder) + linears_of(ref.decoder)
+    ek = NonLinear._engine_optimizer_kwargs(name, {**_OPTIMIZERS[name], **kwargs})
+    ek.pop("optimizer")
+    eng = hip.Mlp("ae", enc + dec[1:], acts, max_batch=batch, latent_layer=2, optimizer=name, **ek)
+    push_params(eng, lins)
+    eng.set_feature_range(r)
+    opt = getattr(torch.optim, name)(ref.parameters(), **kwargs)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=20 * kwargs["lr"], total_steps=steps, cycle_momentum=False)
+    assert abs(opt.param_groups[0]["lr"] - kwargs["lr"]) > 0.1 * kwargs["lr"]   # the constructor has already moved the lr
+    Xd = torch.from_numpy(Xn).cuda()
+    Xt = torch.from_numpy(X)
+    eng.reset_log(16)
+    for i in range(steps):
+        r0 = (i * 97) % (X.shape[0] - batch)
+        eng.set_lr(opt.param_groups[0]["lr"])
+        eng.train_step(Xd, row0=r0, batch=batch)
+        opt.zero_grad()
+        loss, _ = ref.step(Xt[r0:r0 + batch])
+        loss.backward()
+        opt.step()
+        sched.step()
+    for (w, b), lin in zip(eng.get_linears(), lins):
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=2e-5, rtol=2e-4)
+        np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=2e-5, rtol=2e-4)
+    eng.close()
+
+
+def test_batchnorm_is_refused_in_a_data_parallel_step():
+    """a frame-sharded step with batch normalisation would normalise with each rank's local rows (and let the
+    running statistics of the ranks drift apart): dcv_mlp_dp_step refuses it with a message instead of computing something
+    that is no longer the single-process fit.  One rank (global batch = local batch) is the single-process fit and runs."""
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd._lib import DcvError
+
+    class _OneRank:   # the slice of torch.distributed the step touches
+        class ReduceOp:
+            SUM = "sum"
+
+        @staticmethod
+        def all_reduce(t, op=None, group=None, async_op=False):
+            return None
+
+    F, batch = 16, 256
+    X = torch.from_numpy(ar_features(1200, F, 5)).cuda()
+    eng = hip.Mlp("deep_tica", [F, 8, 2], ["tanh", None], max_batch=batch, lag=3, batchnorm=[True, False])
+    push_params(eng, linears_of(torch.nn.Sequential(torch.nn.Linear(F, 8), torch.nn.Linear(8, 2))))
+    eng.reset_log(8)
+    with pytest.raises(DcvError, match="batch normalisation is not implemented for data-parallel"):
+        eng.data_parallel_step(X, _OneRank, 2 * batch, row0=0, batch=batch, train=True)
+    eng.data_parallel_step(X, _OneRank, batch, row0=0, batch=batch, train=True)   # one rank: allowed
+    assert np.isfinite(eng.read_log()[:, 0]).all()
+    eng.close()
+
+
 # ----------------------------------------------------------------------------- calculators: schedulers, validation set
 def _training(**general):
     t = json.loads(json.dumps(TEST_COMMON["training"]))

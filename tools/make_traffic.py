@@ -34,7 +34,9 @@ for d, rows, mode in triples:
             "kernel": k3, "fetch_size_kib": f["FETCH_SIZE"], "write_size_kib": w["WRITE_SIZE"],
             "hbm_bytes_per_launch": (2 * f["FETCH_SIZE"] + w["WRITE_SIZE"]) * 1024,
             "avg_us_in_fetch_pass": f["avg_us"],
-            "effective_clock_ghz": f["GRBM_GUI_ACTIVE"] / 8 / f["avg_us"] / 1e3,
+            # no clock field: GRBM_GUI_ACTIVE / 8 / dispatch time reads HIGH on dispatches shorter than ~0.3 ms (the counter
+            # window is wider than the dispatch; MI355X_MICROARCH.md, DVFS give-back) -- round 3 printed 2.76-2.80 "GHz" for
+            # 24 us kernels on a 2.4 GHz part.  The in-kernel clock comes from s_memtime / s_memrealtime stamps (tools/gemm_bench).
         }
     tables.append({
         "source": f"rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE / WRITE_SIZE passes (tools/prof_cmd.sh) of bench.py, {d}",

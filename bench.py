@@ -45,9 +45,10 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=15.0)
     p.add_argument("--profile-every", type=int, default=0,
-                   help="HIP events (stamped with the launch's own begin / end) on the layer-0 products of every n-th timed step; 0 (default) = "
-                        "every step when --steps <= 100, every 8th otherwise.  The first timed step -- the one right behind the barrier: "
-                        "idle clocks, cold L2 -- is never sampled")
+                   help="HIP events (stamped with the launch's own begin / end) on the layer-0 products of every n-th timed step, forward "
+                        "product and weight gradient on different steps; 0 (default) = every 4th step when --steps <= 100, every 8th otherwise; "
+                        "1 = both products of every step (costs ~15 us per step).  The first timed step -- the one right behind the "
+                        "barrier: idle clocks, cold L2 -- is never sampled")
     p.add_argument("--large-batch", type=int, default=524208,
                    help="second measurement ('large_batch'): 8 x (65536 - lag) pairs -- every rank's step covers whole 128-row "
                         "tiles at 1/2/4/8 GPUs when the rows of x_t and x_lag are shared; 0 disables")
@@ -192,12 +193,24 @@ class Fit:
 
     @staticmethod
     def sample_plan(steps, profile_every):
-        """(every, sampled step numbers): every timed step when the run is short (the driver's 20 steps gave THREE samples at
-        every 8th step in round 3, one of them the step right behind the barrier -- 29.8 us live against 22.8 us in every
-        rocprofv3 trace), every 8th in long runs; never step 0 (idle clocks, cold L2 behind the synchronisation)."""
-        every = profile_every if profile_every > 0 else (1 if steps <= 100 else 8)
-        picked = [i for i in range(steps) if i % every == 0 and (i > 0 or steps == 1)]
-        return every, picked
+        """{step: kinds left UNSAMPLED on that step} for the steps that carry events.  A launch stamped through
+        hipExtLaunchKernel costs the step ~7 us of command-processor work (measured in round 4: both layer-0 products of every
+        one of 20 steps stamped = 0.119 ms / step against 0.0986 unstamped), so the two products are sampled on DIFFERENT
+        steps, each every `every`-th step: every = 4 in a run of <= 100 steps (the driver's 20 steps: five samples of each
+        product; round 3 had three, one of them the step right behind the barrier -- 29.8 us live against 22.8 us in every
+        rocprofv3 trace), 8 otherwise.  Step 0 (idle clocks, cold L2 behind the synchronisation) is never sampled."""
+        every = profile_every if profile_every > 0 else (4 if steps <= 100 else 8)
+        if steps == 1:
+            return {0: ()}
+        if every == 1:
+            return {i: () for i in range(1, steps)}
+        plan = {}
+        for i in range(1, steps):
+            if i % every == 1 % every:
+                plan[i] = ("wgrad", "dgrad")      # the forward product only
+            elif i % every == (1 + every // 2) % every:
+                plan[i] = ("fwd",)                 # the weight gradient only
+        return plan
 
     def run(self, steps, warmup, profile_every, with_validation=True):
         """Times exactly `steps` optimiser steps between barriers; returns (seconds [max over ranks], per-kernel
@@ -210,8 +223,7 @@ class Fit:
         for i in range(warmup):
             self.train_step(i)
         self.barrier()
-        _, picked = self.sample_plan(steps, profile_every)
-        picked = set(picked)
+        picked = self.sample_plan(steps, profile_every)
         self.samples = len(picked)
         if picked:
             eng.profile_begin(len(picked) + 1, 1)
@@ -219,7 +231,7 @@ class Fit:
         self.val_timed = 0
         for i in range(steps):
             if picked:
-                eng.profile_pause(i not in picked)
+                eng.profile_pause(i not in picked, picked.get(i, ()))
             self.train_step(i)
             if with_validation and (i + 1) % self.steps_per_epoch == 0:
                 self.validation_pass()
@@ -291,9 +303,9 @@ class Fit:
                 "kernel": kname, "rows_per_launch": R, "flop_per_launch": fl, "avg_ms": ms,
                 "timing_source": "HIP events on the launch stream stamped with that launch's own begin / end (hipExtLaunchKernel through "
                                  "dcv_mlp_profile_*: the interval rocprofv3 --kernel-trace reports, profiles/), live inside bench.py: "
-                                 f"{getattr(self, 'samples', 0)} sampled timed steps (every step of a run of <= 100 steps, every 8th otherwise; never the "
-                                 "first one behind the barrier)",
-                "samples": getattr(self, "samples", 0),
+                                 "each layer-0 product on every 4th timed step of a run of <= 100 steps (8th otherwise), the two products on "
+                                 "different steps, never the first step behind the barrier",
+                "samples": {k: int(c) for k, c in sorted(((f"layer{l}.{kk}", cnt) for (l, kk), (_, cnt) in prof.items()))},
                 "all_kernels_ms": {k: v[1] for k, v in sorted(per.items())}, "note": note}
 
     def close(self):
@@ -385,8 +397,7 @@ def run_c2(a, steps, warmup, cpu_seconds):
     for i in range(30 + warmup):
         train_step(i)
     torch.cuda.synchronize()
-    _, picked = Fit.sample_plan(steps, a.profile_every)
-    picked = set(picked)
+    picked = {i: () for i in Fit.sample_plan(steps, a.profile_every)}   # one fused launch per step: both classes are that launch
     if picked:
         eng.profile_begin(len(picked) + 1, 1)
     t0 = time.perf_counter()
@@ -460,7 +471,7 @@ def run_ref_small(a, steps, cpu_seconds):
         for bs in (128, 4096):
             fit = Fit(hip, None, X, dims, acts, lag, bs, 1, a.lr, linears, n, shuffled=True)
             elapsed, prof, log = fit.run(steps, 30, a.profile_every, with_validation=False)
-            fused = bool(fit.eng.lib.dcv_mlp_fused_small(fit.eng.h)) if hasattr(fit.eng.lib, "dcv_mlp_fused_small") else False
+            fused = fit.eng.last_path() == 2
             fl = 12.0 * sw * bs
             us = elapsed / steps * 1e6
             rec = {"network": "-".join(map(str, dims)), "batch": bs, "value": steps * bs / elapsed, "unit": "frames/s", "us_per_step": us,

@@ -80,6 +80,7 @@ SIGNATURES = {
     "dcv_mlp_set_momentum": (C.c_int, [_P, C.c_double]),
     "dcv_mlp_dropout_mask": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "dcv_mlp_dropout_step": (_I64, [_P]),
+    "dcv_mlp_last_path": (_I32, [_P]),
     "dcv_gemm_tn_split": (C.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P]),
     "dcv_mlp_set_row_sharing": (C.c_int, [_P, _I32]),
     "dcv_mlp_set_feature_range": (C.c_int, [_P, _P, _P]),

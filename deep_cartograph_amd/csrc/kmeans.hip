@@ -442,7 +442,7 @@ __device__ __forceinline__ double np_norm(const double* x, const double* c, int 
         for (int q = 8; q < kKmMaxD; ++q)
             if (q >= full && q < d) res = __dadd_rn(res, sq[q]);
     }
-    return sqrt(res);
+    return __dsqrt_rn(res);   // numpy's sqrt is correctly rounded; the plain device sqrt is allowed 1 ulp (seen: one distance in eleven off by an ulp)
 }
 
 // grid.x = point blocks, grid.y = centroid.  part[(j*nblocks + b)] = (dist, row)
@@ -511,11 +511,12 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
         s_c[j][q] = j < kc ? centers[(int64_t)(j0 + j) * D + q] : 0.0;
     }
     __syncthreads();
-    double best[KC];
+    double best[KC], bthr[KC];   // smallest sum of squares so far, and the value below which a root is certainly smaller
     int64_t besti[KC];
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
         best[j] = INFINITY;
+        bthr[j] = INFINITY;
         besti[j] = INT64_MAX;
     }
     const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
@@ -553,10 +554,16 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
                         const double df = x[u][q] - s_c[j][q];
                         res = __dadd_rn(res, __dmul_rn(df, df));
                     }
-                    const double v = sqrt(res);
-                    if (v < best[j]) {   // increasing i: strict '<' keeps the first index
-                        best[j] = v;
-                        besti[j] = i;
+                    // numpy takes argmin over the ROUNDED distances sqrt(res): the first index wins among equal ones.  The
+                    // square root (a ~30-instruction float64 sequence, 120 M of them at 20M x 6: what bounded this pass) is
+                    // needed only where two sums of squares are so close that their roots could round to the same double:
+                    // below best * (1 - 2^-50) the rounded root is strictly smaller, at or above best it is not smaller.
+                    if (res < best[j]) {
+                        if (res < bthr[j] || __dsqrt_rn(res) < __dsqrt_rn(best[j])) {
+                            best[j] = res;
+                            bthr[j] = res * (1.0 - 0x1p-50);
+                            besti[j] = i;
+                        }
                     }
                 }
             }
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
     }
 #pragma unroll
     for (int j = 0; j < KC; ++j) {
-        double b = best[j];
+        double b = __dsqrt_rn(best[j]);   // from here on the rounded distances, as numpy's argmin sees them
         int64_t bi = besti[j];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {

@@ -11,6 +11,7 @@
 // loss runs in float64 on the device from batch statistics that a data-parallel caller
 // all-reduces, so nothing returns to the host inside an epoch.
 #include "mlp_state.h"
+#include "tica_head.h"
 #include <new>
 #include <math.h>
 
@@ -639,143 +640,6 @@ static TicaGradFn tica_grad_fn(int d) {
     }
 }
 
-// tica_grad_body spread over the lanes of one wave (D <= 4: lane l < D*D owns matrix element (l / D, l % D)): the
-// single-thread form is a chain of ~2000 dependent float64 instructions (8 us); here every matrix product is one step
-// of D multiply-adds per lane and only the Cholesky factorisation (D columns) and the two triangular solves (one
-// column of the inverse per lane) stay sequential.  Matrices live in LDS; the wave is its own barrier.
-template <int D>
-struct TicaWaveLds {
-    double mu[D], ml[D], invL[D];
-    double C0[D * D], Ct[D * D], L[D * D], A[D * D], K[D * D], T[D * D];
-};
-__device__ __forceinline__ void wave_sync_lds() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-template <int D>
-__device__ __forceinline__ void tica_grad_wave(TicaWaveLds<D>& w, const double* __restrict__ stats, double Bg, double reg,
-                                               double* __restrict__ gradp, double* __restrict__ log, int* __restrict__ log_count,
-                                               int log_cap, int log_width, int lane) {
-    const int i = lane / D, j = lane % D;
-    const bool el = lane < D * D;
-    const double invB = 1.0 / Bg;
-    const double* Stt = stats + 2 * D;
-    const double* Stl = stats + 2 * D + D * D;
-    if (lane < D) {
-        w.mu[lane] = stats[lane] * invB;
-        w.ml[lane] = stats[D + lane] * invB;
-    }
-    wave_sync_lds();
-    if (el) {
-        w.C0[lane] = 0.5 * (Stt[i * D + j] + Stt[j * D + i]) * invB - w.mu[i] * w.mu[j];
-        const double cij = Stl[i * D + j] * invB - w.mu[i] * w.ml[j];
-        const double cji = Stl[j * D + i] * invB - w.mu[j] * w.ml[i];
-        w.Ct[lane] = 0.5 * (cij + cji);
-        w.L[lane] = 0.0;
-    }
-    wave_sync_lds();
-    // Cholesky of C0 + reg I, column by column
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        if (lane == 0) {
-            double s = w.C0[k * D + k] + reg;
-#pragma unroll
-            for (int m = 0; m < D; ++m)
-                if (m < k) s -= w.L[k * D + m] * w.L[k * D + m];
-            const double lkk = sqrt(s);
-            w.L[k * D + k] = lkk;
-            w.invL[k] = s > 0.0 ? 1.0 / lkk : NAN;
-        }
-        wave_sync_lds();
-        if (lane < D && lane > k) {   // L[lane][k]
-            double s = w.C0[lane * D + k];
-#pragma unroll
-            for (int m = 0; m < D; ++m)
-                if (m < k) s -= w.L[lane * D + m] * w.L[k * D + m];
-            w.L[lane * D + k] = s * w.invL[k];
-        }
-        wave_sync_lds();
-    }
-#pragma unroll
-    for (int k = 0; k < D; ++k) ok = ok && !(w.invL[k] != w.invL[k]);
-    // A = (L L^T)^-1: lane c < D solves L y = e_c, L^T a = y (column c of A)
-    if (lane < D) {
-        const int c = lane;
-        double y[D], a[D];
-#pragma unroll
-        for (int r = 0; r < D; ++r) {
-            double s = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < D; ++m)
-                if (m < r) s -= w.L[r * D + m] * y[m];
-            y[r] = s * w.invL[r];
-        }
-#pragma unroll
-        for (int rr = 0; rr < D; ++rr) {
-            const int r = D - 1 - rr;
-            double s = y[r];
-#pragma unroll
-            for (int m = 0; m < D; ++m)
-                if (m > r) s -= w.L[m * D + r] * a[m];
-            a[r] = s * w.invL[r];
-        }
-#pragma unroll
-        for (int r = 0; r < D; ++r) w.A[r * D + c] = a[r];
-    }
-    wave_sync_lds();
-    if (el) {   // K = A Ct
-        double s = 0.0;
-#pragma unroll
-        for (int m = 0; m < D; ++m) s += w.A[i * D + m] * w.Ct[m * D + j];
-        w.K[lane] = s;
-    }
-    wave_sync_lds();
-    double Tij = 0.0;
-    if (el) {   // T = K A (= A Ct A)
-#pragma unroll
-        for (int m = 0; m < D; ++m) Tij += w.K[i * D + m] * w.A[m * D + j];
-        w.T[lane] = Tij;
-    }
-    wave_sync_lds();
-    if (gradp && el) {
-        double g0 = 0.0;
-#pragma unroll
-        for (int m = 0; m < D; ++m) g0 += w.K[i * D + m] * w.T[m * D + j];
-        const double Gt = -(w.T[i * D + j] + w.T[j * D + i]);
-        gradp[D + lane] = 4.0 * g0 * invB;               // (2/B) G0, G0 = 2 K T
-        gradp[D + D * D + lane] = Gt * invB;             // (1/B) Gtau
-    }
-    if (gradp && lane < D) {
-        gradp[lane] = w.mu[lane];
-        double cs = 0.0;
-#pragma unroll
-        for (int m = 0; m < D; ++m) cs += -(w.T[lane * D + m] + w.T[m * D + lane]) * (w.ml[m] - w.mu[m]);
-        gradp[D + 2 * D * D + lane] = -cs * invB;
-    }
-    const int slot = *log_count;
-    if (slot < log_cap) {
-        double* rec = log + (int64_t)slot * log_width;
-        if (lane == 0) {
-            double loss = 0.0;   // -tr(K K), summed in the order of the single-thread form
-#pragma unroll
-            for (int a = 0; a < D; ++a)
-#pragma unroll
-                for (int b = 0; b < D; ++b) loss -= w.K[a * D + b] * w.K[b * D + a];
-            rec[0] = ok ? loss : NAN;
-            rec[1] = Bg;
-        }
-        if (el) {
-            rec[2 + lane] = w.C0[lane];
-            rec[2 + D * D + lane] = w.Ct[lane];
-        }
-        if (lane < D) rec[2 + 2 * D * D + lane] = w.mu[lane];
-    }
-    wave_sync_lds();
-    if (lane == 0) *log_count = slot + 1;
-}
-
 // the wave-parallel loss head as a launch of its own: the data-parallel path, where the batch statistics are all-reduced
 // between the statistics kernel and the head (the single-thread form above is a chain of ~2000 dependent float64
 // instructions, 8 us; this one ~3 us)
@@ -805,14 +669,6 @@ static TicaGradWaveFn tica_grad_wave_fn(int d) {
 // the chip, few enough partials for the last block's ordered sum.  One launch: the block that finishes last adds the
 // partials up in block order and -- on one GPU, where nothing is all-reduced in between (fused.on) -- goes straight
 // on to the d x d loss head (tica_grad_body), saving the launch of tica_grad_kernel.
-struct FusedHead {
-    int on;            // run tica_grad_body in the last block
-    double Bg, reg;
-    double* gradp;     // null: evaluation only
-    double* log;
-    int* log_count;
-    int log_cap, log_width;
-};
 template <int D>
 __global__ __launch_bounds__(256) void tica_stats_rows_kernel(const float* __restrict__ F, int64_t ld, int B, int lag_off,
                                                               int rows_per_block, double* __restrict__ part, unsigned* __restrict__ ticket,
@@ -1260,20 +1116,26 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-static inline bool prof_on(const dcv_mlp* m, int layer) {
-    return m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap && (m->prof_level > 1 || layer == 0);
+// kind: 0 forward, 1 weight gradient, 2 input gradient (-1: any).  Every class (layer, kind) counts its own samples: the
+// host may sample the kinds on different steps (dcv_mlp_profile_pause: a profiled launch costs ~7 us of command-processor
+// work, so bench.py staggers them instead of stamping both layer-0 products of every step)
+static inline bool prof_on(const dcv_mlp* m, int layer, int kind = -1) {
+    if (!(m->prof_level > 0 && !m->prof_paused && (m->prof_level > 1 || layer == 0))) return false;
+    if (kind < 0) return true;
+    return ((m->prof_kind_off >> kind) & 1) == 0 && m->prof_cnt[(size_t)3 * layer + kind] < m->prof_cap;
 }
 // which = 0: before the launch(es) of the class, 1: after.  The pair of events is offered to the block engine's launcher
 // (g_launch_ev, common.h), which stamps it with the kernel's own begin / end; when the launch in between did not take it
 // (the fused small-network step, a grouped launch), the events are recorded around the launch instead.
 static inline void prof_mark(dcv_mlp* m, int layer, int kind, int which, hipStream_t s) {
-    if (!prof_on(m, layer)) return;
+    if (!prof_on(m, layer, kind)) return;
     const size_t cls = (size_t)3 * layer + kind;
-    hipEvent_t* ev = &m->prof_ev[(cls * m->prof_cap + m->prof_step) * 2];
+    hipEvent_t* ev = &m->prof_ev[(cls * m->prof_cap + m->prof_cnt[cls]) * 2];
     if (which == 0) {
         (void)hipEventRecord(ev[0], s);
         if (g_launch_ev.start == nullptr) g_launch_ev = LaunchEvents{ev[0], ev[1]};   // (one offer at a time: a grouped launch is bracketed by two classes)
     } else {
+        m->prof_cnt[cls] += 1;
         if (g_launch_taken == ev[0]) {   // the launcher took the pair: both events carry the kernel's own times
             g_launch_taken = nullptr;
             return;
@@ -1382,6 +1244,7 @@ static void head_plan(const dcv_mlp* m, int64_t R, int64_t* rows_per_block, int6
 static void mlp_free(dcv_mlp* m) {
     if (!m) return;
     snet_free(m);
+    snet_dt_free(m);
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->opt_aux); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
@@ -1480,7 +1343,12 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->drop_rank = 0;
     m->snet = nullptr;
     m->snet_tried = false;
-    m->prof_level = m->prof_cap = m->prof_step = 0;
+    m->snet_dt = nullptr;
+    m->snet_dt_tried = false;
+    m->snet_fwd_valid = false;
+    m->last_path = 0;
+    m->prof_level = m->prof_cap = 0;
+    m->prof_kind_off = 0;
     for (int i = 0; i < 4; ++i) { m->gexec[i] = nullptr; m->gwarm[i] = false; }
     m->graph_on = graph_enabled();
     m->graph_off = false;
@@ -1700,6 +1568,10 @@ extern "C" int dcv_mlp_set_rank(dcv_mlp* m, int32_t rank) {
 
 extern "C" int dcv_mlp_layer_output(dcv_mlp* m, int32_t layer, int64_t rows, float* out_d, void* stream) {
     DCV_REQUIRE(m && out_d && layer >= 0 && layer < m->L && rows >= 1 && rows <= m->rows_cap, "dcv_mlp_layer_output: bad arguments");
+    if (m->last_path != 0) {
+        set_error("dcv_mlp_layer_output: the last forward ran as a fused small-network launch (activations never left LDS); set DCV_NO_SNET=1");
+        return DCV_ESTATE;
+    }
     const LayerPlan& p = m->layers[layer];
     DCV_CHECK_HIP(hipMemcpy2DAsync(out_d, (size_t)p.out * sizeof(float), p.H, (size_t)p.ldh * sizeof(float), (size_t)p.out * sizeof(float),
                                    (size_t)rows, hipMemcpyDeviceToDevice, as_stream(stream)));
@@ -1707,6 +1579,7 @@ extern "C" int dcv_mlp_layer_output(dcv_mlp* m, int32_t layer, int64_t rows, flo
 }
 
 extern "C" int64_t dcv_mlp_dropout_step(const dcv_mlp* m) { return m ? m->drop_step : 0; }
+extern "C" int32_t dcv_mlp_last_path(const dcv_mlp* m) { return m ? m->last_path : -1; }
 
 extern "C" int dcv_mlp_dropout_mask(dcv_mlp* m, int32_t layer, int64_t step, int64_t rows, float* out_d, void* stream) {
     DCV_REQUIRE(m && out_d && layer >= 0 && layer < m->L && rows >= 1 && step >= 0, "dcv_mlp_dropout_mask: bad arguments");
@@ -1923,6 +1796,24 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
     DCV_REQUIRE(batch >= 1 && batch <= m->desc.max_batch, "dcv_mlp_forward: batch=%d exceeds max_batch=%d", batch, m->desc.max_batch);
     DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_forward: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
     hipStream_t s = as_stream(stream);
+    m->snet_fwd_valid = false;
+    m->last_path = 0;
+    if (m->desc.model == DCV_MODEL_DEEPTICA && !(m->snet_dt_tried && m->snet_dt == nullptr)) {
+        // a network that fits in LDS: forward, batch statistics and (one-GPU steps) the loss head in ONE launch (snet_dt.hip)
+        if (fuse_head) DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
+        prof_mark(m, 0, 0, 0, s);
+        const int rcs = snet_dt_forward(m, Xn_d, ld, idx_d, row0, batch, fuse_head, fuse_head != 2, s);
+        if (rcs < 0) return rcs;
+        if (rcs == DCV_OK) {
+            prof_mark(m, 0, 0, 1, s);
+            m->snet_fwd_valid = fuse_head != 2;
+            m->last_path = 2;
+            m->last_batch = batch;
+            m->head_done = fuse_head != 0;
+            return DCV_OK;
+        }
+        if (prof_on(m, 0)) g_launch_ev = LaunchEvents{};   // not applicable: the layer-by-layer path marks its own launches
+    }
     const RowMap rm = batch_rows(m, idx_d, row0, batch);
     const int64_t R = rows_of(m, idx_d, batch);
     int rc = run_forward(m, Xn_d, ld, rm, R, m->L, s, fuse_head != 2);   // the one-GPU evaluation step has no backward: no sign masks
@@ -2087,6 +1978,48 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
         }
         m->head_done = false;
         if (!train) return DCV_OK;
+        if (m->last_path == 2) {
+            // the forward ran fused (snet_dt.hip): one backward launch from its blob, then the reduction (+ optimiser)
+            if (!m->snet_fwd_valid) {
+                set_error("dcv_mlp_backward: the fused forward of this batch kept no activations (evaluation step)");
+                return DCV_ESTATE;
+            }
+            ReduceArgsView v;
+            prof_mark(m, 0, 1, 0, s);
+            int rcb = snet_dt_backward(m, batch, &v, s);
+            if (rcb) return rcb;
+            prof_mark(m, 0, 1, 1, s);
+            ReduceArgs raf{};
+            raf.L = L;
+            for (int l = 0; l < L; ++l) {
+                const LayerPlan& p = m->layers[l];
+                ReduceDesc& rd = raf.l[l];
+                rd.slab = v.slab[l];
+                rd.bpart = v.bpart[l];
+                rd.w_off = p.w_off;
+                rd.b_off = p.b_off;
+                rd.w_count = (int64_t)p.out * p.in;
+                rd.out = p.out;
+                rd.splits = v.splits[l];
+                rd.bblocks = v.bblocks[l];
+            }
+            bool upper = false;
+            if (L > 1 && m->upper_cb && !fuse_opt) {   // data-parallel overlap hook: the upper layers' gradients first
+                rcb = launch_reduce(m, raf, 1, L, false, OptArgs{}, s);
+                if (rcb) return rcb;
+                upper = true;
+                m->upper_cb(m->upper_cb_user);
+            }
+            OptArgs oaf{};
+            if (fuse_opt) {
+                rcb = first_step_state(m, s);
+                if (rcb) return rcb;
+                oaf = next_opt_args(m);
+            }
+            rcb = launch_reduce(m, raf, 0, upper ? 1 : L, fuse_opt, oaf, s);
+            if (rcb) return rcb;
+            return DCV_OK;
+        }
         fused_head = head_fusable(m);
         if (!fused_head) {
             hipLaunchKernelGGL(tica_dF_kernel, dim3((unsigned)cdiv(R, 256)), dim3(256), 0, s, net_out, last.ldh, batch, m->d_out,
@@ -2251,7 +2184,6 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     }
     int rc2 = launch_reduce(m, ra, 0, upper_done ? 1 : L, fuse_opt, oa, s);   // layer 0 only when the upper layers went out early
     if (rc2) return rc2;
-    if (m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
     return DCV_OK;
 }
 
@@ -2264,20 +2196,22 @@ extern "C" int dcv_mlp_profile_begin(dcv_mlp* m, int32_t max_steps, int32_t leve
         m->prof_ev.push_back(e);
     }
     m->prof_cap = max_steps;
-    m->prof_step = 0;
+    m->prof_cnt.assign((size_t)3 * m->L, 0);
+    m->prof_kind_off = 0;
+    m->prof_paused = false;
     m->prof_level = level;
     return DCV_OK;
 }
 
 extern "C" int dcv_mlp_profile_pause(dcv_mlp* m, int32_t paused) {
     DCV_REQUIRE(m, "dcv_mlp_profile_pause: null");
-    m->prof_paused = paused != 0;
+    m->prof_paused = (paused & 1) != 0;
+    m->prof_kind_off = (paused >> 1) & 7;   // bit 1 / 2 / 3: forward / weight-gradient / input-gradient launches carry no events
     return DCV_OK;
 }
 
 extern "C" int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h) {
     DCV_REQUIRE(m && ms_h && counts_h, "dcv_mlp_profile_end: null argument");
-    const int steps = m->prof_step;
     const int level = m->prof_level;
     m->prof_level = 0;
     for (int c = 0; c < 3 * m->L; ++c) {
@@ -2286,6 +2220,7 @@ extern "C" int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h) 
         const int layer = c / 3, kind = c % 3;
         if (level < 2 && layer != 0) continue;
         if (kind == 2 && layer == 0) continue;  // the first layer has no dgrad
+        const int steps = (size_t)c < m->prof_cnt.size() ? m->prof_cnt[c] : 0;
         for (int i = 0; i < steps; ++i) {
             hipEvent_t a = m->prof_ev[((size_t)c * m->prof_cap + i) * 2 + 0];
             hipEvent_t b = m->prof_ev[((size_t)c * m->prof_cap + i) * 2 + 1];
@@ -2434,11 +2369,11 @@ static int snet_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* i
     if (rc) return rc;
     prof_mark(m, 0, 0, 1, s);
     prof_mark(m, 0, 1, 1, s);
-    if (train && m->prof_level > 0 && !m->prof_paused && m->prof_step < m->prof_cap) m->prof_step += 1;
     m->fwd_train = train != 0;
     if (m->fwd_train) m->cur_step = m->drop_step++;
     m->head_done = false;
     m->last_batch = batch;
+    m->last_path = 1;
     if (!train) return DCV_OK;
     ReduceArgs ra;
     ra.L = m->L;

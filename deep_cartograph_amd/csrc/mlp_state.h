@@ -56,6 +56,10 @@ struct dcv_mlp {
     uint32_t drop_rank;        // mixed into the key of the dropout counters (dcv_mlp_set_rank): the ranks of a data-parallel run draw independent masks
     void* snet;                // plan of the fused small-network step (snet.hip) or null
     bool snet_tried;           // the plan was attempted once (null afterwards = not applicable)
+    void* snet_dt;             // plan of the fused small-network Deep-TICA forward / backward (snet_dt.hip) or null
+    bool snet_dt_tried;
+    bool snet_fwd_valid;       // the last forward went through snet_dt_forward and left its blob for the backward
+    int last_path;             // path of the last step / forward: 0 layer by layer, 1 fused autoencoder step, 2 fused Deep-TICA kernels
     float* dZ[2];
     int64_t ld_dz;
     double* stats;             // device
@@ -83,7 +87,9 @@ struct dcv_mlp {
     int32_t last_batch;
     int no_row_sharing;        // diagnostic: evaluate contiguous Deep-TICA batches as two separate halves
     // optional per-kernel timing with HIP events on the launch stream (bench.py roofline)
-    int prof_level, prof_cap, prof_step;
+    int prof_level, prof_cap;
+    int prof_kind_off;                // kinds (bit 0 fwd, 1 wgrad, 2 dgrad) whose launches are not sampled right now
+    std::vector<int> prof_cnt;        // samples taken per class
     std::vector<hipEvent_t> prof_ev;  // [class][step][2], class = 3*layer + {0 fwd, 1 wgrad, 2 dgrad}
 };
 
@@ -101,6 +107,11 @@ struct ReduceArgsView {
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int32_t batch, int train, ReduceArgsView* ra,
                  hipStream_t s);
 void snet_free(dcv_mlp* m);
+// snet_dt.hip: Deep-TICA forward (+ statistics, + loss head) and backward of a network that fits in LDS; 1 = not applicable
+int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
+                    hipStream_t s);
+int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t s);
+void snet_dt_free(dcv_mlp* m);
 // bn.hip
 int bn_forward(dcv_mlp* m, int l, int64_t row0, int64_t rows, bool train, hipStream_t s);
 int bn_backward(dcv_mlp* m, int l, float* dz, int64_t ld_dz, int halves, int64_t rows_half, int act, float hscale, const DropCfg& drop,

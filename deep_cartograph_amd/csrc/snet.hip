@@ -15,25 +15,11 @@
 // the network is far too small for the matrix rate to matter, and no operand splitting is needed.
 // A wave owns 16-row groups: TR = 32 -> waves (row group, column-tile parity); the k-slot permutation of gemm.h lets
 // one ds_read_b128 feed four MFMA steps (lane (n, q) holds k = k0 + 4q + s in step s, identically for A and B).
-#include <hip/hip_ext.h>
-#include "mlp_state.h"
+#include "snet.h"
 #include <new>
 
 namespace dcv {
 
-typedef float sv4f __attribute__((ext_vector_type(4)));
-
-constexpr int kSnetThreads = 512;   // 8 waves: two per SIMD, one hides the other's LDS and MFMA latency
-constexpr int kSnetWaves = kSnetThreads / 64;
-
-struct SnetLayer {
-    int in, out, pin, pout, act;
-    int nk_in, nk_out;          // pin / 16, pout / 16
-    int u4_begin, c4_shift;     // staging: first 16-byte unit of this layer's weight image in the flat unit space; log2(pin / 4)
-    int64_t w_off, b_off;       // flat parameter buffer
-    int lw, lb, pws;            // LDS float offsets of the weight image [pout][pws] and the bias [pout]; pws = pin + 4
-    int64_t pw_off, pb_off;     // gradient partials: part + pw_off + wg * out * in ; part + pb_off + wg * out
-};
 struct SnetArgs {
     SnetLayer l[DCV_MAX_LAYERS];
     int L;
@@ -65,132 +51,6 @@ struct SnetArgs {
     do {                                                                                        \
         if (a.stamps != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[k] = __builtin_amdgcn_s_memrealtime(); \
     } while (0)
-
-__device__ __forceinline__ sv4f mfma4(float a, float b, sv4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-// Contraction lengths are compile-time (NK chunks of 16; the plan pads every width to 16 * 2^j): the fragment reads of
-// a tile are issued back to back, the MFMAs run in up to four independent accumulator chains, no branch in between.
-// (With run-time trip counts hipcc emitted ds_read -> s_waitcnt lgkmcnt(0) -> 4 dependent MFMAs -> branch per chunk:
-// 1.2 us of fixed cost per layer, 51 us per fused step.)
-template <int NK>
-struct SnetFrags {
-    sv4f f[NK];
-    __device__ __forceinline__ void load(const float* p) {   // p: this lane's row, offset 4 * q; chunk j at p + 16 j
-#pragma unroll
-        for (int j = 0; j < NK; ++j) f[j] = *reinterpret_cast<const sv4f*>(p + 16 * j);
-    }
-};
-template <int NK>
-__device__ __forceinline__ sv4f snet_chain_sum(sv4f (&acc)[(NK < 4 ? NK : 4)]) {
-    constexpr int C = NK < 4 ? NK : 4;
-    sv4f r = acc[0];
-#pragma unroll
-    for (int c = 1; c < C; ++c) r += acc[c];
-    return r;
-}
-// D[r][c] = sum_k A[r][k] W[c][k]  (forward: A = activations of the wave's 16 rows, W row-major [out][in])
-template <int NK>
-__device__ __forceinline__ sv4f snet_fwd_tile(const SnetFrags<NK>& A, const float* bp) {
-    constexpr int C = NK < 4 ? NK : 4;
-    SnetFrags<NK> B;
-    B.load(bp);
-    sv4f acc[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = sv4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NK; ++j) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[j % C] = mfma4(A.f[j][s], B.f[j][s], acc[j % C]);
-    }
-    return snet_chain_sum<NK>(acc);
-}
-// D[r][i] = sum_o dZ[r][o] W[o][i]  (input gradient: A = dZ rows, B = a column block of W read down the rows)
-template <int NK>
-__device__ __forceinline__ sv4f snet_dgrad_tile(const SnetFrags<NK>& A, const float* bp, int pws) {
-    constexpr int C = NK < 4 ? NK : 4;
-    float b[NK][4];
-#pragma unroll
-    for (int j = 0; j < NK; ++j)
-#pragma unroll
-        for (int s = 0; s < 4; ++s) b[j][s] = bp[(16 * j + s) * pws];
-    sv4f acc[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc[c] = sv4f{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NK; ++j) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc[j % C] = mfma4(A.f[j][s], b[j][s], acc[j % C]);
-    }
-    return snet_chain_sum<NK>(acc);
-}
-// D[o][i] = sum_r dZ[r][o] Hin[r][i], r < TR  (weight gradient of the tile)
-template <int TR>
-__device__ __forceinline__ sv4f snet_wgrad_tile(const float* ap, int psz, const float* bp, int psh) {
-    float av[TR / 4], bv[TR / 4];
-#pragma unroll
-    for (int s = 0; s < TR / 4; ++s) {
-        av[s] = ap[4 * s * psz];
-        bv[s] = bp[4 * s * psh];
-    }
-    sv4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < TR / 4; s += 2) {
-        acc0 = mfma4(av[s], bv[s], acc0);
-        acc1 = mfma4(av[s + 1], bv[s + 1], acc1);
-    }
-    return acc0 + acc1;
-}
-
-// activation with the switch outside the element loop
-__device__ __forceinline__ sv4f snet_act4(int act, sv4f z) {
-    sv4f h;
-    switch (act) {
-        case DCV_ACT_NONE: h = z; break;
-        case DCV_ACT_LEAKY_RELU:
-#pragma unroll
-            for (int v = 0; v < 4; ++v) h[v] = z[v] > 0.f ? z[v] : 0.01f * z[v];
-            break;
-        case DCV_ACT_RELU:
-#pragma unroll
-            for (int v = 0; v < 4; ++v) h[v] = z[v] > 0.f ? z[v] : 0.f;
-            break;
-        default:
-#pragma unroll
-            for (int v = 0; v < 4; ++v) h[v] = act_fwd(act, z[v]);
-            break;
-    }
-    return h;
-}
-__device__ __forceinline__ sv4f snet_actgrad4(int act, sv4f h) {
-    sv4f g;
-    switch (act) {
-        case DCV_ACT_NONE: g = sv4f{1.f, 1.f, 1.f, 1.f}; break;
-        case DCV_ACT_LEAKY_RELU:
-#pragma unroll
-            for (int v = 0; v < 4; ++v) g[v] = h[v] > 0.f ? 1.f : 0.01f;
-            break;
-        case DCV_ACT_RELU:
-#pragma unroll
-            for (int v = 0; v < 4; ++v) g[v] = h[v] > 0.f ? 1.f : 0.f;
-            break;
-        default:
-#pragma unroll
-            for (int v = 0; v < 4; ++v) g[v] = act_grad_from_out(act, h[v]);
-            break;
-    }
-    return g;
-}
-
-constexpr int kSnetMaxTiles = 8;   // column tiles of a layer per wave (input gradients are held in registers across a barrier)
-
-#define SNET_NK_SWITCH(nk, CALL)          \
-    switch (nk) {                         \
-        case 1: { CALL(1) } break;        \
-        case 2: { CALL(2) } break;        \
-        case 4: { CALL(4) } break;        \
-        case 8: { CALL(8) } break;        \
-        default: { CALL(16) } break;      \
-    }
 
 template <int TR>
 __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
@@ -466,11 +326,6 @@ struct SnetPlan {
     int2* stage_tab;     // device copy of the staging table
 };
 
-static bool snet_disabled() {
-    static const bool off = [] { const char* e = getenv("DCV_NO_SNET"); return e && e[0] == '1'; }();
-    return off;
-}
-
 // Builds the plan once per engine.  Not applicable (returns false): wide layers, dropout, a network that does not fit
 // in LDS with at least 16-row tiles.
 static bool snet_build(dcv_mlp* m) {
@@ -479,43 +334,11 @@ static bool snet_build(dcv_mlp* m) {
     if (!pl) return false;
     SnetArgs& a = pl->base;
     a.L = m->L;
-    int fl = 0, u4 = 0;
+    int fl = 0;
     int64_t per_wg = 0;
     std::vector<int2> tab;
-    for (int l = 0; l < m->L; ++l) {
-        const LayerPlan& p = m->layers[l];
-        SnetLayer& y = a.l[l];
-        y.in = p.in; y.out = p.out; y.act = p.act;
-        auto pad = [](int w) { int k = 1; while (16 * k < w) k *= 2; return 16 * k; };   // 16 * 2^j: compile-time contraction lengths
-        y.pin = pad(p.in);
-        y.pout = pad(p.out);
-        if (y.pin > 256 || y.pout > 256) { delete pl; return false; }
-        y.nk_in = y.pin / 16;
-        y.nk_out = y.pout / 16;
-        y.u4_begin = u4;
-        u4 += y.pout * (y.pin / 4);
-        y.c4_shift = 0;
-        while ((1 << y.c4_shift) < y.pin / 4) ++y.c4_shift;
-        y.w_off = p.w_off; y.b_off = p.b_off;
-        y.pws = y.pin + 4;
-        y.lw = fl; fl += y.pout * y.pws;
-        y.lb = fl; fl += y.pout;
-        per_wg += (int64_t)p.out * p.in + p.out;
-        const bool vec = (p.in % 4 == 0) && (p.w_off % 4 == 0);
-        for (int o = 0; o < y.pout; ++o)
-            for (int c = 0; c < y.pin / 4; ++c) {
-                const int nv = o < p.out ? (p.in - 4 * c >= 4 ? 4 : (p.in - 4 * c > 0 ? p.in - 4 * c : 0)) : 0;
-                tab.push_back(make_int2(nv > 0 ? (int)(p.w_off + (int64_t)o * p.in + 4 * c) : -1,
-                                        (y.lw + o * y.pws + 4 * c) | (nv << 20) | ((vec && nv == 4 ? 1 : 0) << 24)));
-            }
-        for (int c = 0; c < y.pout / 4; ++c) {
-            const int nv = p.out - 4 * c >= 4 ? 4 : (p.out - 4 * c > 0 ? p.out - 4 * c : 0);
-            tab.push_back(make_int2(nv > 0 ? (int)(p.b_off + 4 * c) : -1, (y.lb + 4 * c) | (nv << 20) | ((nv == 4 && p.b_off % 4 == 0 ? 1 : 0) << 24)));
-        }
-    }
+    if (!snet_layout(m, a.l, tab, nullptr, fl, per_wg)) { delete pl; return false; }
     pl->per_wg = per_wg;
-    (void)u4;
-    if (fl >= (1 << 20) || m->n_params >= (1ll << 31)) { delete pl; return false; }
     pl->stage_tab = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&pl->stage_tab), tab.size() * sizeof(int2)) != hipSuccess ||
         hipMemcpy(pl->stage_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {

@@ -1,0 +1,645 @@
+// Fused Deep-TICA step of a SMALL network (the reference's own sizes: cv_calculator.py:2569-2590 builds 54-16-8-2 in its
+// test configuration, F-15-15-d from tools/train_colvars/default_config.yml): every weight resident in one CU's LDS, as in
+// snet.hip -- but the Deep-TICA loss couples ALL samples of the batch (the d x d covariances of the network outputs), so
+// one grid-wide dependency sits between the forward and the backward pass.  A kernel boundary is the cheapest grid-wide
+// synchronisation on this part: the step is TWO fused launches plus the gradient reduction,
+//
+//   snet_dt_fwd_kernel   a workgroup takes TR / 2 PAIRS: rows [0, TR/2) of its tile are the x_t rows, rows [TR/2, TR) the
+//                        x_lag rows of the same pairs (gathered through the RowMap: contiguous, gathered and two-half
+//                        batches alike) -- both halves of a pair in ONE tile, so the 2d + 2d^2 batch statistics of its
+//                        pairs are formed from LDS.  Forward chain with the activations kept in LDS; statistics partial
+//                        (float64, pair order); the tile's activations leave as one contiguous blob (write-through); the
+//                        ticketed last arriver (handoff.h) adds the partials in block order and -- one-GPU steps -- runs
+//                        the wave-parallel d x d loss head (tica_head.h).  An evaluation step ends here.
+//   snet_dt_bwd_kernel   stages the weights of layers >= 1 (the input gradients need them) and its blob back into LDS,
+//                        evaluates the loss gradient of its pairs in float64 from the head's matrices (the arithmetic of
+//                        tica_dF_kernel / head_backward_kernel), walks back through the layers as snet_ae_kernel does and
+//                        leaves one gradient partial per workgroup and layer for reduce_grads_quad_kernel + the optimiser.
+//
+// Three launches instead of eight for a 3-layer network, none of them a matrix product over a few thousand rows on 516
+// workgroups.  Row sharing is given up: a contiguous batch evaluates 2 B rows instead of B + lag -- at these
+// widths the step is latency, not flops.  A data-parallel step uses the same two kernels with the head left to
+// tica_grad_wave_kernel behind the statistics all-reduce.  Not taken (the layer-by-layer path runs): d > 4, dropout, batch
+// normalisation, a width above 256, a network that does not fit in LDS, more than 512 tiles (DCV_NO_SNET=1 forces it off).
+#include "snet.h"
+#include "tica_head.h"
+#include <new>
+
+namespace dcv {
+
+struct SnetDtArgs {
+    SnetLayer l[DCV_MAX_LAYERS];
+    int L;
+    const int2* stage_tab;        // staging table (snet_layout), entries ordered by layer
+    int stage_n;                  // all entries (forward)
+    int stage_bwd0;               // first entry of layer 1: the backward kernel stages [stage_bwd0, stage_n)
+    int lh[DCV_MAX_LAYERS + 1];   // LDS float offset of H_l [TR][ps_l]   (H_0 = the input tile)
+    int ps[DCV_MAX_LAYERS + 1];
+    int act_len;                  // floats of the activation region [lh[0], lh[0] + act_len): the blob of a workgroup
+    const float* params;
+    const float* Xn;
+    int64_t ld;
+    RowMap rows;                  // half = batch: logical row p < B is x_t of pair p, row B + p its x_lag
+    int B;                        // pairs of this rank's batch
+    int store_blob;
+    float* blob;                  // [workgroups][blob_stride]
+    int64_t blob_stride;
+    double* spart;                // statistics partials [workgroups][2d + 2d^2]
+    unsigned* ticket;
+    double* stats;
+    FusedHead fused;
+    const double* gradp;          // backward: [mu d | Gu d*d | Gv d*d | c d]
+    float* part;                  // backward: gradient partials
+};
+
+template <int NARGS>
+__device__ __forceinline__ unsigned touch_kernargs() {
+    unsigned x = 0;
+    const __attribute__((address_space(4))) unsigned* kp = (const __attribute__((address_space(4))) unsigned*)__builtin_amdgcn_kernarg_segment_ptr();
+#pragma unroll
+    for (int off = 0; off < NARGS; off += 64) x ^= kp[off / 4];
+    return x;
+}
+
+template <int TR, int D>
+__global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a) {
+    constexpr int NT = kSnetThreads, HP = TR / 2;
+    constexpr int RG = TR / 16, CG = kSnetWaves / RG;
+    constexpr int W = 2 * D + 2 * D * D;
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    __shared__ TicaWaveLds<D> s_head;
+    __shared__ double s_stat[W];
+    __shared__ unsigned s_flag;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int rg = wave % RG, cg = wave / RG;
+    const int q = lane >> 4, n = lane & 15;
+    const int L = a.L;
+    const unsigned ka_touch = touch_kernargs<(int)sizeof(SnetDtArgs)>();
+    // ---- input tile: local row r is pair p0 + r % HP, half r / HP
+    const int64_t p0 = (int64_t)blockIdx.x * HP;
+    const int F0 = a.l[0].in, pin0 = a.l[0].pin, ps0 = a.ps[0];
+    float* H0 = sl + a.lh[0];
+    const bool x_vec = (F0 & 3) == 0 && (a.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Xn) & 15) == 0;
+    const int x_sh = a.l[0].c4_shift, x_tot = TR << x_sh;
+    auto src_row = [&](int r) -> int64_t {   // matrix row of local row r, -1 past the batch
+        const int half = r >= HP ? 1 : 0;
+        const int64_t p = p0 + (r - half * HP);
+        return p < a.B ? a.rows.template get<true>(half ? (int64_t)a.B + p : p) : -1;
+    };
+    float4 xv[4];
+    bool x_issued = false;
+    auto issue_x = [&]() {
+        const int f4 = F0 >> 2;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
+            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < x_tot && c < f4) {
+                const int64_t row = src_row(r);
+                if (row >= 0) xv[u] = *reinterpret_cast<const float4*>(a.Xn + row * a.ld + 4 * c);
+            }
+        }
+    };
+    // ---- stage every weight image and bias (snet.hip: one flat table, twelve loads in flight, two dependent round trips)
+    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
+        int2 e[12];
+        float4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = i0 + NT * u;
+            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e[u].x >= 0) {
+                const float* src = a.params + e[u].x;
+                const int nv = (e[u].y >> 20) & 7;
+                if ((e[u].y >> 24) & 1) {
+                    v[u] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v[u].x = src[0];
+                    if (nv > 1) v[u].y = src[1];
+                    if (nv > 2) v[u].z = src[2];
+                    if (nv > 3) v[u].w = src[3];
+                }
+            }
+        }
+        if (x_vec && !x_issued) {   // the rows of X ride along the data round trip
+            x_issued = true;
+            issue_x();
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+    }
+    if (x_vec && !x_issued) issue_x();
+    asm volatile("" ::"s"(ka_touch));
+    if (x_vec) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
+            if (i < x_tot) *reinterpret_cast<float4*>(H0 + r * ps0 + 4 * c) = xv[u];
+        }
+    } else {
+        for (int i = t; i < TR * pin0; i += NT) {
+            const int r = i / pin0, c = i - r * pin0;
+            float v = 0.f;
+            if (c < F0) {
+                const int64_t row = src_row(r);
+                if (row >= 0) v = a.Xn[row * a.ld + c];
+            }
+            H0[r * ps0 + c] = v;
+        }
+    }
+    __syncthreads();
+    // ---- forward chain
+    for (int l = 0; l < L; ++l) {
+        const SnetLayer& y = a.l[l];
+        const float* Hin = sl + a.lh[l];
+        float* Hout = sl + a.lh[l + 1];
+        const int psin = a.ps[l], pso = a.ps[l + 1];
+        const float* ap = Hin + (rg * 16 + n) * psin + 4 * q;
+        const float* Wl = sl + y.lw + n * y.pws + 4 * q;
+#define SNET_FWD(NK)                                                                                          \
+        SnetFrags<NK> A;                                                                                       \
+        A.load(ap);                                                                                            \
+        for (int ct = cg; ct < y.nk_out; ct += CG) {                                                           \
+            const sv4f acc = snet_fwd_tile<NK>(A, Wl + ct * 16 * y.pws);                                       \
+            const int col = ct * 16 + n;                                                                       \
+            const float bias = sl[y.lb + col];                                                                 \
+            sv4f h = snet_act4(y.act, acc + bias);                                                             \
+            if (col >= y.out) h = sv4f{0.f, 0.f, 0.f, 0.f};                                                    \
+            _Pragma("unroll") for (int v = 0; v < 4; ++v) Hout[(rg * 16 + 4 * q + v) * pso + col] = h[v];      \
+        }
+        SNET_NK_SWITCH(y.nk_in, SNET_FWD)
+#undef SNET_FWD
+        __syncthreads();
+    }
+    // ---- statistics partial of the tile's pairs: [sum f_t | sum f_lag | sum f_t f_t^T | sum f_t f_lag^T], float64, pair order
+    {
+        const float* FL = sl + a.lh[L];
+        const int psL = a.ps[L];
+        const int64_t left = (int64_t)a.B - p0;
+        const int nvalid = left >= HP ? HP : (left > 0 ? (int)left : 0);
+        if (t < W) {
+            double s = 0.0;
+            if (t < D) {
+                for (int pl = 0; pl < nvalid; ++pl) s += (double)FL[pl * psL + t];
+            } else if (t < 2 * D) {
+                for (int pl = 0; pl < nvalid; ++pl) s += (double)FL[(HP + pl) * psL + t - D];
+            } else if (t < 2 * D + D * D) {
+                const int e = t - 2 * D, i = e / D, j = e - i * D;
+                for (int pl = 0; pl < nvalid; ++pl) s += (double)FL[pl * psL + i] * (double)FL[pl * psL + j];
+            } else {
+                const int e = t - 2 * D - D * D, i = e / D, j = e - i * D;
+                for (int pl = 0; pl < nvalid; ++pl) s += (double)FL[pl * psL + i] * (double)FL[(HP + pl) * psL + j];
+            }
+            handoff_store(a.spart + (int64_t)blockIdx.x * W + t, s);
+        }
+    }
+    // ---- the tile's activations (input tile, every layer's output) for the backward launch: one contiguous blob
+    if (a.store_blob) {
+        const float* src = sl + a.lh[0];
+        float* dst = a.blob + (int64_t)blockIdx.x * a.blob_stride;
+        for (int i = 4 * t; i < a.act_len; i += 4 * NT) {
+            const sv4f v = *reinterpret_cast<const sv4f*>(src + i);
+            handoff_store16(dst + i, v);   // write-through: nothing left for the write-back at the end of the launch
+        }
+    }
+    // ---- last workgroup: the partials in block order, then the d x d loss head
+    if (!handoff_arrive_last(a.ticket, gridDim.x, &s_flag)) return;
+    {
+        constexpr int G = NT / W;
+        double* s_grp = reinterpret_cast<double*>(sl);   // [G][W]: the weight images are dead
+        const int g = t / W, o = t - g * W;
+        if (g < G) {
+            double s = 0.0;
+            for (unsigned b0 = g; b0 < gridDim.x; b0 += 8 * G) {   // eight loads in flight, added in block order
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned b = b0 + (unsigned)u * G;
+                    v[u] = handoff_load(a.spart + (int64_t)(b < gridDim.x ? b : b0) * W + o);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (b0 + (unsigned)u * G < gridDim.x) s += v[u];
+            }
+            s_grp[g * W + o] = s;
+        }
+        __syncthreads();
+        if (t < W) {
+            double s = 0.0;
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) s += s_grp[g2 * W + t];
+            a.stats[t] = s;
+            s_stat[t] = s;
+        }
+        if (a.fused.on) {
+            __syncthreads();
+            if (wave == 0)
+                tica_grad_wave<D>(s_head, s_stat, a.fused.Bg, a.fused.reg, a.fused.gradp, a.fused.log, a.fused.log_count, a.fused.log_cap,
+                                  a.fused.log_width, lane);
+        }
+    }
+}
+
+template <int TR, int D>
+__global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a) {
+    constexpr int NT = kSnetThreads, HP = TR / 2;
+    constexpr int RG = TR / 16, CG = kSnetWaves / RG;
+    constexpr int NG = 2 * D + 2 * D * D;   // mu | Gu | Gv | c
+    extern __shared__ __attribute__((aligned(16))) float sl[];
+    __shared__ double s_g[NG];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int rg = wave % RG, cg = wave / RG;
+    const int q = lane >> 4, n = lane & 15;
+    const int L = a.L;
+    const unsigned ka_touch = touch_kernargs<(int)sizeof(SnetDtArgs)>();
+    const int64_t p0 = (int64_t)blockIdx.x * HP;
+    // ---- stage the weight images of layers >= 1 (the input gradients read them; no bias, no layer 0) and the blob.
+    //      Order of issue: table entries, the first eight blob units, the weight data (needs the entries: loads return in
+    //      order, so waiting for the entries does not wait for the blob), LDS stores at the end.
+    const float* bsrc = a.blob + (int64_t)blockIdx.x * a.blob_stride;
+    float* bdst = sl + a.lh[0];
+    const int n4 = a.act_len >> 2;
+    float4 bv[8];
+    bool blob_issued = false;
+    auto issue_blob = [&]() {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = t + NT * u;
+            bv[u] = i < n4 ? *reinterpret_cast<const float4*>(bsrc + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    for (int i0 = a.stage_bwd0 + t; i0 < a.stage_n; i0 += 12 * NT) {
+        int2 e[12];
+        float4 v[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = i0 + NT * u;
+            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
+        if (!blob_issued) {
+            blob_issued = true;
+            issue_blob();
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e[u].x >= 0) {
+                const float* src = a.params + e[u].x;
+                const int nv = (e[u].y >> 20) & 7;
+                if ((e[u].y >> 24) & 1) {
+                    v[u] = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v[u].x = src[0];
+                    if (nv > 1) v[u].y = src[1];
+                    if (nv > 2) v[u].z = src[2];
+                    if (nv > 3) v[u].w = src[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 12; ++u)
+            if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+    }
+    if (!blob_issued) issue_blob();
+    if (t < NG) s_g[t] = a.gradp[t];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int i = t + NT * u;
+        if (i < n4) *reinterpret_cast<float4*>(bdst + 4 * i) = bv[u];
+    }
+    for (int i0 = t + 8 * NT; i0 < n4; i0 += 8 * NT) {   // larger tiles: the rest of the blob, eight units in flight
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + NT * u;
+            w[u] = i < n4 ? *reinterpret_cast<const float4*>(bsrc + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + NT * u;
+            if (i < n4) *reinterpret_cast<float4*>(bdst + 4 * i) = w[u];
+        }
+    }
+    asm volatile("" ::"s"(ka_touch));
+    __syncthreads();
+    // ---- loss gradient of the tile's pairs, float64, rounded once (tica_dF_kernel: the rows of the exact gradient sum to
+    //      zero over the batch; see DESIGN.md section 2, noise-driven parameters): dL/df_t = Gu u + Gv v + c, dL/df_lag = Gv u
+    //      with u = f_t - mu, v = f_lag - mu; times act'(f) of the last layer; written over f (H_L becomes dZ_L)
+    {
+        float* FL = sl + a.lh[L];
+        const int psL = a.ps[L];
+        const int act_last = a.l[L - 1].act;
+        const int pl = t / D, i = t - pl * D;
+        const bool mine = t < HP * D;
+        const bool valid = mine && p0 + pl < a.B;
+        float ft[D], fg[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            ft[k] = mine ? FL[pl * psL + k] : 0.f;
+            fg[k] = mine ? FL[(HP + pl) * psL + k] : 0.f;
+        }
+        __syncthreads();   // every thread has read its pair before any value is overwritten
+        if (mine) {
+            float gt = 0.f, gl = 0.f;
+            if (valid) {
+                const double* mu = s_g;
+                const double* Gu = s_g + D;
+                const double* Gv = Gu + D * D;
+                const double* cv = Gv + D * D;
+                double g1 = cv[i], g2 = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    const double u = (double)ft[k] - mu[k], v = (double)fg[k] - mu[k];
+                    g1 = fma(Gu[i * D + k], u, g1);
+                    g1 = fma(Gv[i * D + k], v, g1);
+                    g2 = fma(Gv[i * D + k], u, g2);
+                }
+                float fti = ft[0], fgi = fg[0];   // ft[i] / fg[i] without a dynamically indexed register array
+#pragma unroll
+                for (int k = 1; k < D; ++k) {
+                    fti = i == k ? ft[k] : fti;
+                    fgi = i == k ? fg[k] : fgi;
+                }
+                gt = (float)g1 * act_grad_from_out(act_last, fti);
+                gl = (float)g2 * act_grad_from_out(act_last, fgi);
+            }
+            FL[pl * psL + i] = gt;
+            FL[(HP + pl) * psL + i] = gl;
+        }
+        __syncthreads();
+    }
+    // ---- backward chain (snet_ae_kernel): dZ_l lives in the buffer of H_{l+1}; dZ_{l-1} is written over H_l once the weight
+    //      gradient of layer l (which reads H_l) has been formed by every wave
+    for (int l = L - 1; l >= 0; --l) {
+        const SnetLayer& y = a.l[l];
+        const float* dZ = sl + a.lh[l + 1];
+        float* Hin = sl + a.lh[l];
+        const int psz = a.ps[l + 1], psh = a.ps[l];
+        sv4f dg[kSnetMaxTiles];
+        if (l > 0) {
+            const float* ap = dZ + (rg * 16 + n) * psz + 4 * q;
+            const float* Wl = sl + y.lw + (4 * q) * y.pws + n;
+#define SNET_DGRAD(NK)                                                                                   \
+            SnetFrags<NK> A;                                                                             \
+            A.load(ap);                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < kSnetMaxTiles; ++j) {                                  \
+                const int it = cg + j * CG;                                                              \
+                if (it < y.nk_in) dg[j] = snet_dgrad_tile<NK>(A, Wl + it * 16, y.pws);                   \
+            }
+            SNET_NK_SWITCH(y.nk_out, SNET_DGRAD)
+#undef SNET_DGRAD
+        }
+        {
+            const int nti = y.nk_in, ntot = y.nk_out * nti;
+            float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.out * y.in;
+            const bool vec_ok = (y.in & 3) == 0 && ((y.pw_off + (int64_t)blockIdx.x * y.out * y.in) & 3) == 0;
+            int ot = 0, it = wave;
+            while (it >= nti) { it -= nti; ++ot; }
+#pragma unroll 2
+            for (int tile = wave; tile < ntot; tile += kSnetWaves) {
+                const sv4f acc = snet_wgrad_tile<TR>(Hin + q * psh + it * 16 + n, psh, dZ + q * psz + ot * 16 + n, psz);
+                const int o = ot * 16 + n, i0 = it * 16 + 4 * q;
+                if (o < y.out) {
+                    float* dst = pw + (int64_t)o * y.in + i0;
+                    if (vec_ok && i0 + 4 <= y.in) {
+                        handoff_store16(dst, acc);
+                    } else {
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+                            if (i0 + v < y.in) dst[v] = acc[v];
+                    }
+                }
+                it += kSnetWaves;
+                while (it >= nti) { it -= nti; ++ot; }
+            }
+            for (int o4 = t; o4 < 4 * y.pout; o4 += NT) {
+                const int o = o4 >> 2, part = o4 & 3;
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < TR / 4; ++r) s += dZ[(part * (TR / 4) + r) * psz + o];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.out + o] = s;
+            }
+        }
+        if (l == 0) break;
+        __syncthreads();   // every wave is done reading H_l
+        const int act_prev = a.l[l - 1].act, out_prev = a.l[l - 1].out;
+#pragma unroll
+        for (int j = 0; j < kSnetMaxTiles; ++j) {
+            const int it = cg + j * CG;
+            if (it < y.nk_in) {
+                const int col = it * 16 + n;
+                float* p = Hin + (rg * 16 + 4 * q) * psh + col;
+                sv4f h;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) h[v] = p[v * psh];
+                const sv4f dh = snet_actgrad4(act_prev, h);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) p[v * psh] = col < out_prev ? dg[j][v] * dh[v] : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+struct SnetDtPlan {
+    int TR;
+    size_t lds_bytes;
+    SnetDtArgs base;
+    int64_t per_wg;        // floats of one workgroup's gradient partials (dense)
+    int2* stage_tab;
+    float* part;           // gradient partials
+    int64_t part_floats;
+    float* blob;
+    int64_t blob_floats;
+    double* spart;         // statistics partials
+    int64_t spart_n;
+    int64_t last_wg;       // workgroups of the last forward (the backward launches the same grid)
+};
+
+static bool snet_dt_build(dcv_mlp* m) {
+    if (m->desc.model != DCV_MODEL_DEEPTICA || m->any_drop || m->any_bn || m->d_out > 4 || m->d_out < 1 || snet_disabled()) return false;
+    SnetDtPlan* pl = new (std::nothrow) SnetDtPlan();
+    if (!pl) return false;
+    *pl = SnetDtPlan{};
+    SnetDtArgs& a = pl->base;
+    a.L = m->L;
+    int fl = 0;
+    int64_t per_wg = 0;
+    std::vector<int2> tab;
+    int tab_begin[DCV_MAX_LAYERS];
+    if (!snet_layout(m, a.l, tab, tab_begin, fl, per_wg)) { delete pl; return false; }
+    pl->per_wg = per_wg;
+    if (hipMalloc(reinterpret_cast<void**>(&pl->stage_tab), tab.size() * sizeof(int2)) != hipSuccess ||
+        hipMemcpy(pl->stage_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (pl->stage_tab) (void)hipFree(pl->stage_tab);
+        delete pl;
+        return false;
+    }
+    a.stage_tab = pl->stage_tab;
+    a.stage_n = (int)tab.size();
+    a.stage_bwd0 = m->L > 1 ? tab_begin[1] : (int)tab.size();
+    const size_t lds_max = 160 * 1024 - 8 * 1024;   // static LDS of the kernels (loss head, flags) and a margin
+    const int TR = 32;
+    int f = fl;
+    for (int l = 0; l <= m->L; ++l) {
+        const int P = l == 0 ? a.l[0].pin : a.l[l - 1].pout;
+        a.ps[l] = P + 4;
+        a.lh[l] = f;
+        f += TR * (P + 4);
+    }
+    a.act_len = f - a.lh[0];
+    if (f < 2048) f = 2048;   // the last arriver sums the statistics partials in the first 4 KB
+    if ((size_t)f * sizeof(float) > lds_max) {
+        (void)hipFree(pl->stage_tab);
+        delete pl;
+        return false;
+    }
+    pl->TR = TR;
+    pl->lds_bytes = (size_t)f * sizeof(float);
+    m->snet_dt = pl;
+    return true;
+}
+
+void snet_dt_free(dcv_mlp* m) {
+    SnetDtPlan* pl = static_cast<SnetDtPlan*>(m->snet_dt);
+    if (!pl) return;
+    if (pl->part) (void)hipFree(pl->part);
+    if (pl->blob) (void)hipFree(pl->blob);
+    if (pl->spart) (void)hipFree(pl->spart);
+    if (pl->stage_tab) (void)hipFree(pl->stage_tab);
+    delete pl;
+    m->snet_dt = nullptr;
+}
+
+template <class T>
+static bool grow(T** p, int64_t* have, int64_t need) {
+    if (*have >= need) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    if (hipMalloc(reinterpret_cast<void**>(p), (size_t)need * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *have = need;
+    return true;
+}
+
+template <class K>
+static int snet_dt_launch(K kern, int slot, const SnetDtPlan* pl, const SnetDtArgs& a, int64_t nwg, hipStream_t s) {
+    static int attr_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per kernel instantiation: 0 unknown, 1 set, -1 refused by the runtime
+    if (attr_state[slot] == 0) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024);
+        if (e != hipSuccess) (void)hipGetLastError();
+        attr_state[slot] = e == hipSuccess ? 1 : -1;
+    }
+    if (attr_state[slot] < 0) return 1;
+    if (g_launch_ev.start != nullptr) {   // a profiled launch: events stamped with the kernel's own begin / end (common.h)
+        const LaunchEvents ev = g_launch_ev;
+        g_launch_ev = LaunchEvents{};
+        g_launch_taken = ev.start;
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), (uint32_t)pl->lds_bytes, s, ev.start, ev.stop, 0u, a);
+    } else {
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), pl->lds_bytes, s, a);
+    }
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+
+// Fused forward of one Deep-TICA batch (+ batch statistics, + the loss head when head != 0: 1 = training, the head's
+// matrices go to m->gradp; 2 = evaluation).  keep_blob: a backward may follow.  Returns 1 when the fused form does not
+// apply (the caller runs the layer-by-layer path), DCV_OK when the launch was enqueued.
+int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
+                    hipStream_t s) {
+    static const int64_t kMaxBytes = 64ll << 20;
+    if (m->snet_dt == nullptr) {
+        if (m->snet_dt_tried || !snet_dt_build(m)) {
+            m->snet_dt_tried = true;
+            return 1;
+        }
+        m->snet_dt_tried = true;
+    }
+    SnetDtPlan* pl = static_cast<SnetDtPlan*>(m->snet_dt);
+    const int HP = pl->TR / 2;
+    const int64_t nwg = cdiv(batch, HP);
+    const int W = m->stats_len;
+    if (nwg > 512 || nwg * pl->per_wg * (int64_t)sizeof(float) > kMaxBytes || nwg * pl->base.act_len * (int64_t)sizeof(float) > kMaxBytes) return 1;
+    if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
+    if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)pl->base.act_len)) return 1;
+    SnetDtArgs a = pl->base;
+    a.params = m->params;
+    a.Xn = Xn_d;
+    a.ld = ld;
+    a.rows = RowMap{idx_d, row0, batch, m->desc.lag};
+    a.B = batch;
+    a.store_blob = keep_blob ? 1 : 0;
+    a.blob = pl->blob;
+    a.blob_stride = a.act_len;
+    a.spart = pl->spart;
+    a.ticket = m->ticket;
+    a.stats = m->stats;
+    a.fused = FusedHead{0, 0.0, 0.0, nullptr, nullptr, nullptr, 0, 0};
+    if (head) a.fused = FusedHead{1, (double)batch, m->desc.tica_reg, head == 1 ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width};
+    a.gradp = nullptr;
+    a.part = nullptr;
+    pl->last_wg = nwg;
+    switch (m->d_out) {
+        case 1: return snet_dt_launch(snet_dt_fwd_kernel<32, 1>, 0, pl, a, nwg, s);
+        case 2: return snet_dt_launch(snet_dt_fwd_kernel<32, 2>, 1, pl, a, nwg, s);
+        case 3: return snet_dt_launch(snet_dt_fwd_kernel<32, 3>, 2, pl, a, nwg, s);
+        default: return snet_dt_launch(snet_dt_fwd_kernel<32, 4>, 3, pl, a, nwg, s);
+    }
+}
+
+// Fused backward of the batch whose forward snet_dt_forward ran last (its blob is in place): gradient partials for the
+// reduction, whose descriptors go to `ra`.  m->gradp holds the loss head's matrices.
+int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t s) {
+    SnetDtPlan* pl = static_cast<SnetDtPlan*>(m->snet_dt);
+    if (!pl || !pl->blob) {
+        set_error("snet_dt_backward: no fused forward to go back through");
+        return DCV_ESTATE;
+    }
+    const int64_t nwg = cdiv(batch, pl->TR / 2);
+    if (nwg != pl->last_wg) {
+        set_error("snet_dt_backward: batch=%d does not match the fused forward", batch);
+        return DCV_ESTATE;
+    }
+    const int64_t part_need = nwg * pl->per_wg + 8 * (int64_t)m->L;
+    if (!grow(&pl->part, &pl->part_floats, part_need)) {
+        set_error("snet_dt_backward: out of device memory (%lld floats of gradient partials)", (long long)part_need);
+        return DCV_ENOMEM;
+    }
+    SnetDtArgs a = pl->base;
+    int64_t off = 0;
+    for (int l = 0; l < m->L; ++l) {
+        SnetLayer& y = a.l[l];
+        y.pw_off = off; off += (nwg * (int64_t)y.out * y.in + 3) / 4 * 4;
+        y.pb_off = off; off += (nwg * (int64_t)y.out + 3) / 4 * 4;
+        ra->slab[l] = pl->part + y.pw_off;
+        ra->bpart[l] = pl->part + y.pb_off;
+        ra->splits[l] = (int)nwg;
+        ra->bblocks[l] = (int)nwg;
+    }
+    a.params = m->params;
+    a.B = batch;
+    a.blob = pl->blob;
+    a.blob_stride = a.act_len;
+    a.gradp = m->gradp;
+    a.part = pl->part;
+    switch (m->d_out) {
+        case 1: return snet_dt_launch(snet_dt_bwd_kernel<32, 1>, 4, pl, a, nwg, s);
+        case 2: return snet_dt_launch(snet_dt_bwd_kernel<32, 2>, 5, pl, a, nwg, s);
+        case 3: return snet_dt_launch(snet_dt_bwd_kernel<32, 3>, 6, pl, a, nwg, s);
+        default: return snet_dt_launch(snet_dt_bwd_kernel<32, 4>, 7, pl, a, nwg, s);
+    }
+}
+
+}  // namespace dcv

@@ -526,6 +526,10 @@ class Mlp:
         """beta1 (Adam family) / momentum (SGD, RMSprop) of the following updates (cycled by OneCycleLR)."""
         check(self.lib.dcv_mlp_set_momentum(self.h, float(value)), "dcv_mlp_set_momentum")
 
+    def last_path(self) -> int:
+        """0 = layer by layer, 1 = fused small-network autoencoder step, 2 = fused small-network Deep-TICA kernels."""
+        return int(self.lib.dcv_mlp_last_path(self.h))
+
     def dropout_step(self) -> int:
         return int(self.lib.dcv_mlp_dropout_step(self.h))
 
@@ -694,9 +698,13 @@ class Mlp:
     def profile_begin(self, max_steps: int, level: int = 1):
         check(self.lib.dcv_mlp_profile_begin(self.h, int(max_steps), int(level)), "dcv_mlp_profile_begin")
 
-    def profile_pause(self, paused: bool):
-        """Steps issued while paused carry no events (a timed region can be sampled)."""
-        check(self.lib.dcv_mlp_profile_pause(self.h, 1 if paused else 0), "dcv_mlp_profile_pause")
+    def profile_pause(self, paused: bool, skip_kinds=()):
+        """Steps issued while paused carry no events (a timed region can be sampled); skip_kinds: launch kinds
+        ('fwd', 'wgrad', 'dgrad') left unsampled while not paused."""
+        code = 1 if paused else 0
+        for k in skip_kinds:
+            code |= 2 << ("fwd", "wgrad", "dgrad").index(k)
+        check(self.lib.dcv_mlp_profile_pause(self.h, code), "dcv_mlp_profile_pause")
 
     def profile_end(self):
         """{(layer, kind): (total_ms, launches)} with kind in 'fwd' | 'wgrad' | 'dgrad'."""

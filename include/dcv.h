@@ -290,7 +290,13 @@ int dcv_mlp_set_rank(dcv_mlp* m, int32_t rank);
  * dcv_mlp_set_params resets them to a fresh BatchNorm1d (mean 0, variance 1, 0 batches). */
 int dcv_mlp_bn_state(dcv_mlp* m, int32_t layer, float* running_mean_h, float* running_var_h, int64_t* num_batches_tracked,
                      int32_t set, void* stream);
-/* Test hook: post-activation output of Linear `layer` in the last forward (rows x dims[layer + 1] floats, dense). */
+/* Which code path the last forward / step took: 0 = layer by layer (the MFMA block engine), 1 = the fused small-network
+ * autoencoder step (one launch: snet.hip), 2 = the fused small-network Deep-TICA kernels (forward + statistics + loss head in
+ * one launch, backward in a second: snet_dt.hip).  The fused forms are taken when every weight fits in one CU's LDS
+ * (reference-sized networks, cv_calculator.py:2471-2590); DCV_NO_SNET=1 in the environment forces 0. */
+int32_t dcv_mlp_last_path(const dcv_mlp* m);
+/* Test hook: post-activation output of Linear `layer` in the last forward (rows x dims[layer + 1] floats, dense).
+ * DCV_ESTATE after a fused small-network forward (dcv_mlp_last_path != 0: the activations never left LDS). */
 int dcv_mlp_layer_output(dcv_mlp* m, int32_t layer, int64_t rows, float* out_d, void* stream);
 /* Convenience for one GPU: forward + backward(train=1) + apply. */
 int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
@@ -323,7 +329,10 @@ int dcv_mlp_read_log(dcv_mlp* m, double* out_h, int32_t max_records, int32_t* n_
 int dcv_mlp_profile_begin(dcv_mlp* m, int32_t max_steps, int32_t level);
 int dcv_mlp_profile_end(dcv_mlp* m, double* ms_h, int32_t* counts_h);
 /* Between begin and end: steps issued while paused carry no events (and may go out as graphs), so a timed region can
- * be sampled, e.g. every fourth step. */
+ * be sampled, e.g. every fourth step.  `paused`: bit 0 = no class is sampled; bits 1 / 2 / 3 = the forward / weight-gradient /
+ * input-gradient launches are not sampled (a profiled launch costs the step ~7 us of command-processor work: a caller can
+ * stamp the forward product on one step and the weight gradient on another).  Every class counts its own samples (up to
+ * max_steps each); dcv_mlp_profile_end reports sums and counts per class. */
 int dcv_mlp_profile_pause(dcv_mlp* m, int32_t paused);
 
 /* With DCV_GRAPH=1 in the environment and a non-null stream, dcv_mlp_train_step / forward / backward(train) /

@@ -63,8 +63,8 @@ def test_bench_self_launches_its_ranks():
     ct = cfg["collective_timing"]
     assert ct["statistics"]["bytes"] == 8 * (2 * 4 + 2 * 16) and ct["statistics"]["us_per_allreduce"] > 0
     assert ct["gradients"]["bytes"] == 4 * cfg["params"] and ct["gradients"]["us_per_allreduce"] > 0
-    # every step after the first one behind the barrier is sampled
-    assert line["roofline"]["samples"] == 5 and line["roofline"]["rows_per_launch"] == 2048 + 10
+    # the two layer-0 products are sampled on different steps (every 4th each), never on the first one behind the barrier
+    assert line["roofline"]["samples"] == {"layer0.fwd": 2, "layer0.wgrad": 1} and line["roofline"]["rows_per_launch"] == 2048 + 10
     assert line["large_batch"]["global_batch"] == 65516 and line["large_batch"]["value"] > 0
     assert line["shuffled"]["rows_per_launch"] == 2 * 2048 and line["shuffled"]["value"] > 0
     assert "c2" not in line and "ref_small" not in line      # single-GPU blocks

@@ -1,0 +1,135 @@
+"""Fused small-network Deep-TICA kernels (snet_dt.hip): forward + batch statistics + loss head in one launch, backward in a
+second, on the reference's own network sizes (cv_calculator.py:2569-2590; tools/train_colvars/default_config.yml:45-55).
+Everything is checked against a FLOAT64 run of the autograd oracle on the same float32 parameters and inputs, through the
+same C-ABI entry points as the layer-by-layer path (dcv_mlp_forward / _backward / _train_step / _eval_step)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nn as onn
+from tests.test_mlp_gpu import ar_features, linears_of, normalized, push_params, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dims, acts, n, lag, seed=3):
+    X = ar_features(n, dims[0], 17)
+    Xn, _, _ = normalized(X)
+    torch.manual_seed(seed)
+    ref = onn.DeepTICAModel(dims, acts, None, None, None, 1e-6)
+    return Xn, ref
+
+
+@pytest.mark.parametrize("dims,hidden_act,last_act,n,lag,batch,gather", [
+    ([54, 16, 8, 2], "leaky_relu", None, 900, 1, 128, True),       # the reference's test network, its clamped batch
+    ([54, 15, 15, 2], "leaky_relu", None, 6000, 10, 4096, True),   # default_config.yml layers [15, 15]: widths padded to 16
+    ([54, 15, 15, 2], "tanh", None, 6000, 10, 4096, False),        # contiguous batch: row sharing is given up, same numbers
+    ([20, 7, 1], "relu", None, 400, 3, 37, False),                 # d = 1, a ragged last tile (37 = 2 * 16 + 5 pairs)
+    ([128, 64, 32, 4], "tanh", None, 3000, 5, 1000, True),         # d = 4, wider layers, 63 tiles
+    ([33, 12, 3], "elu", "tanh", 1500, 2, 515, True),              # scalar input loads (33 % 4 != 0), an activation on the outputs
+    ([16, 2], None, None, 300, 1, 100, False),                     # a single Linear: no input gradient at all
+])
+def test_fused_step_matches_float64_autograd(dims, hidden_act, last_act, n, lag, batch, gather):
+    from deep_cartograph_amd import hip
+
+    acts = [hidden_act] * (len(dims) - 2) + [last_act]
+    Xn, ref = _setup(dims, acts, n, lag)
+    ref64 = copy.deepcopy(ref).double()
+    P = Xn.shape[0] - lag
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+    push_params(eng, linears_of(ref.nn))
+    Xd = torch.from_numpy(Xn).cuda()
+    if gather:
+        idx = torch.randperm(P)[:batch].contiguous()
+        kw = dict(idx=idx.cuda())
+    else:
+        idx = torch.arange(5, 5 + batch)
+        kw = dict(row0=5, batch=batch)
+    eng.reset_log(4)
+    eng.forward(Xd, **kw)
+    assert eng.last_path() == 2, "the fused small-network kernels did not take this network"
+    stats = eng.stats_view().cpu().numpy()
+    eng.backward(Xd, **kw)
+    g = eng.grads_view().cpu().numpy()
+    eng.eval_step(Xd, **kw)          # evaluation step: forward + statistics + head, no blob, no gradient
+    rec = eng.read_log()
+    xt = torch.from_numpy(Xn).double()
+    loss, _ = ref64.step(xt[idx], xt[idx + lag])
+    loss.backward()
+    with torch.no_grad():
+        f_t = ref64.forward_nn(xt[idx])
+        f_l = ref64.forward_nn(xt[idx + lag])
+    d = dims[-1]
+    np.testing.assert_allclose(stats[:d], f_t.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[d:2 * d], f_l.sum(0).numpy(), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[2 * d:2 * d + d * d].reshape(d, d), (f_t.T @ f_t).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(stats[2 * d + d * d:].reshape(d, d), (f_t.T @ f_l).numpy(), rtol=2e-5, atol=2e-5)
+    assert len(rec) == 2 and rec[0, 1] == batch and rec[1, 1] == batch
+    assert abs(rec[0, 0] - float(loss)) < 1e-5 * max(1.0, abs(float(loss)))
+    assert rec[1, 0] == rec[0, 0]   # the evaluation step of the same batch: the same partial sums in the same order
+    lins = linears_of(ref64.nn)
+    worst = 0.0
+    for l, lin in enumerate(lins):
+        wo, bo = eng.offsets[l]
+        gw, gb = lin.weight.grad.numpy(), lin.bias.grad.numpy()
+        ew = rel_err(g[wo:wo + gw.size].reshape(gw.shape), gw)
+        worst = max(worst, ew)
+        assert ew < 2e-5, f"layer {l} weight: {ew:.2e}"
+        if l < len(lins) - 1 or last_act is not None:
+            eb = rel_err(g[bo:bo + gb.size], gb)
+            worst = max(worst, eb)
+            assert eb < 2e-5 or np.max(np.abs(gb)) < 1e-9, f"layer {l} bias: {eb:.2e}"
+        else:   # shift invariance of the loss: the exact gradient of the last bias is 0
+            assert np.max(np.abs(g[bo:bo + gb.size])) < 2e-5 * max(1.0, np.max(np.abs(gw))), f"layer {l} bias"
+    print(f"{dims} batch {batch}: worst gradient deviation from float64 = {worst:.2e}")
+    eng.close()
+
+
+def test_fused_training_follows_the_oracle():
+    """40 Adam steps through dcv_mlp_train_step (fused forward + head, fused backward, reduction + Adam: three launches per
+    step) against torch.optim.Adam over the float32 autograd oracle on the same shuffled batches; then a batch too large
+    for the fused form (more than 512 tiles) falls back to the layer-by-layer path inside the same engine."""
+    from deep_cartograph_amd import hip
+
+    dims, acts, lag, batch = [54, 16, 8, 2], ["tanh", "tanh", None], 4, 256
+    Xn, ref = _setup(dims, acts, 5000, lag, seed=9)
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=16384, lag=lag, tica_reg=1e-6, lr=2e-3)
+    push_params(eng, linears_of(ref.nn))
+    opt = torch.optim.Adam(ref.parameters(), lr=2e-3)
+    Xd, Xt = torch.from_numpy(Xn).cuda(), torch.from_numpy(Xn)
+    g = torch.Generator().manual_seed(5)
+    eng.reset_log(64)
+    for _ in range(40):
+        idx = torch.randperm(Xn.shape[0] - lag, generator=g)[:batch].contiguous()
+        eng.train_step(Xd, idx=idx.cuda())
+        assert eng.last_path() == 2
+        opt.zero_grad()
+        loss, _ = ref.step(Xt[idx], Xt[idx + lag])
+        loss.backward()
+        opt.step()
+    rec = eng.read_log()
+    assert len(rec) == 40 and abs(rec[-1, 0] - float(loss)) < 3e-5 * max(1.0, abs(float(loss)))
+    for (w, b), lin in zip(eng.get_linears(), linears_of(ref.nn)[:-1]):
+        np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=3e-6 * max(1.0, float(lin.weight.abs().max())))
+        np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=3e-6)
+    big = ar_features(16500, 54, 3)
+    eng.train_step(torch.from_numpy(normalized(big)[0]).cuda(), row0=0, batch=16384)   # 1024 tiles: the general path
+    assert eng.last_path() == 0
+    eng.close()
+
+
+def test_layer_output_hook_says_when_the_activations_never_left_lds():
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd._lib import DcvError
+
+    dims, acts = [54, 16, 8, 2], ["tanh", "tanh", None]
+    Xn, ref = _setup(dims, acts, 600, 2)
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=128, lag=2)
+    push_params(eng, linears_of(ref.nn))
+    eng.reset_log(2)
+    eng.forward(torch.from_numpy(Xn).cuda(), row0=0, batch=128)
+    with pytest.raises(DcvError, match="fused small-network"):
+        eng.layer_output(0, 128)
+    eng.close()

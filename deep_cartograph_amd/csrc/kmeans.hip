@@ -41,6 +41,39 @@ __device__ __forceinline__ void load_point(const double* __restrict__ P, int64_t
     }
 }
 
+
+// ---- D = 4 float64 coordinates = 32 bytes per point.  A lane that reads its own point issues two 16-byte loads at a
+// 32-byte lane stride: every wave-instruction touches 2 KB of lines and uses half of them (measured 3.9 - 4.2 TB/s where the
+// 16-byte-per-lane contiguous streams of this library reach 5.3).  Instead two wave-instructions each read 1 KB contiguously
+// -- lane l takes 16-byte unit l: half (l & 1) of point l >> 1 of the first, resp. second, 32 points of a 64-point chunk --
+// the two lanes of a pair swap halves (row DPP, quad_perm [1, 0, 3, 2]: no LDS) and every lane ends up with ONE full point:
+// even lanes the point of the first instruction, odd lanes that of the second.
+struct PairUnits {
+    double2 a, b;
+};
+__device__ __forceinline__ int64_t pair_point(int64_t chunk_base, int lane) { return chunk_base + (lane >> 1) + ((lane & 1) ? 32 : 0); }
+__device__ __forceinline__ void pair_issue(const double* __restrict__ P, int64_t chunk_base, int64_t end, int lane, PairUnits& r) {
+    const int64_t pa = chunk_base + (lane >> 1), pb = pa + 32;
+    const int h = 2 * (lane & 1);
+    r.a = pa < end ? *reinterpret_cast<const double2*>(P + pa * 4 + h) : make_double2(0.0, 0.0);
+    r.b = pb < end ? *reinterpret_cast<const double2*>(P + pb * 4 + h) : make_double2(0.0, 0.0);
+}
+__device__ __forceinline__ double dpp_swap_pair(double v) {
+    const long long u = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_mov_dpp((int)(u & 0xFFFFFFFFll), 0xB1, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp((int)(u >> 32), 0xB1, 0xF, 0xF, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ void pair_finish(const PairUnits& r, int lane, double (&x)[4]) {
+    const double sax = dpp_swap_pair(r.a.x), say = dpp_swap_pair(r.a.y);   // the partner's unit of the first instruction
+    const double sbx = dpp_swap_pair(r.b.x), sby = dpp_swap_pair(r.b.y);
+    const bool odd = (lane & 1) != 0;
+    x[0] = odd ? sbx : r.a.x;
+    x[1] = odd ? sby : r.a.y;
+    x[2] = odd ? r.b.x : sax;
+    x[3] = odd ? r.b.y : say;
+}
+
 // acc layout per block: [sums k*d | counts k | inertia | changed]
 __global__ __launch_bounds__(kKmThreads) void kmeans_step_kernel(const double* __restrict__ P, int64_t n, int d,
                                                                  const double* __restrict__ offset,
@@ -162,67 +195,98 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const doubl
     // U points per thread are requested before any of them is used: with one point per thread in flight a wave keeps
     // 2 KB outstanding and the pass is bound by load latency (1.4 TB/s), not by HBM
     constexpr int U = 4;
-    for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)kKmThreads * U) {
-        double xs[U][D];
-        int32_t olds[U];
+    // one point: label, inertia, changed count, sums (the arithmetic is the same whichever way the point was loaded)
+    auto take_point = [&](const double (&xr)[D], int64_t i, int32_t old) {
+        double x[D];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + (int64_t)u * kKmThreads;
-            if (i < end) {
-                const double* p = P + i * D;
-                if constexpr (D % 2 == 0) {
+        for (int c = 0; c < D; ++c) x[c] = xr[c] - off[c];   // X -= X_mean, as KMeans.fit does (a zero offset changes nothing)
+        int best = 0;
+        double bestv = INFINITY;
 #pragma unroll
-                    for (int c = 0; c < D; c += 2) {
-                        const double2 v = *reinterpret_cast<const double2*>(p + c);
-                        xs[u][c] = v.x;
-                        xs[u][c + 1] = v.y;
-                    }
-                } else {
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < k) {
+                double dot = 0.0;
 #pragma unroll
-                    for (int c = 0; c < D; ++c) xs[u][c] = p[c];
+                for (int c = 0; c < D; ++c) dot += x[c] * s_c[j * D + c];
+                const double v = s_cn[j] - 2.0 * dot;
+                if (v < bestv) {   // first minimum wins (sklearn lloyd_iter_chunked_dense)
+                    bestv = v;
+                    best = j;
                 }
-                olds[u] = labels[i];
             }
         }
+        double dist = 0.0;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + (int64_t)u * kKmThreads;
-            if (i >= end) break;
-            double x[D];
+        for (int c = 0; c < D; ++c) {
+            const double df = x[c] - s_c[best * D + c];
+            dist += df * df;
+        }
+        acc[KMAX * D + KMAX] += dist;
+        if (mindist) mindist[i] = dist;
+        if (old != best) acc[KMAX * D + KMAX + 1] += 1.0;
+        labels[i] = best;
+        // acc[j] += (best == j) ? x : 0 as ONE fused multiply-add per value with a 0 / 1 multiplier: fma(1, x, acc) is the
+        // correctly rounded acc + x and fma(0, x, acc) is acc (finite x) -- the sums a select + add gives
 #pragma unroll
-            for (int c = 0; c < D; ++c) x[c] = xs[u][c] - off[c];   // X -= X_mean, as KMeans.fit does (a zero offset changes nothing)
-            const int32_t old = olds[u];
-            int best = 0;
-            double bestv = INFINITY;
+        for (int j = 0; j < KMAX; ++j) {
+            if (j < k) {
+                const double mj = best == j ? 1.0 : 0.0;
 #pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-                if (j < k) {
-                    double dot = 0.0;
+                for (int c = 0; c < D; ++c) acc[j * D + c] = fma(mj, x[c], acc[j * D + c]);
+                acc[KMAX * D + j] += mj;
+            }
+        }
+    };
+    if constexpr (D == 4) {
+        // 64-point chunks, wave w of the block takes chunks w, w + 4, ...; U chunks requested before any is used (pair loads: above)
+        const int64_t nchunk = (end - begin + 63) / 64;
+        for (int64_t c0 = wave; c0 < nchunk; c0 += 4 * U) {
+            PairUnits pu[U];
+            int32_t olds[U];
 #pragma unroll
-                    for (int c = 0; c < D; ++c) dot += x[c] * s_c[j * D + c];
-                    const double v = s_cn[j] - 2.0 * dot;
-                    if (v < bestv) {   // first minimum wins (sklearn lloyd_iter_chunked_dense)
-                        bestv = v;
-                        best = j;
+            for (int u = 0; u < U; ++u) {
+                const int64_t cb = begin + (c0 + 4 * u) * 64;
+                pair_issue(P, cb, end, lane, pu[u]);
+                const int64_t i = pair_point(cb, lane);
+                olds[u] = i < end ? labels[i] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t cb = begin + (c0 + 4 * u) * 64;
+                double xr[D];
+                pair_finish(pu[u], lane, xr);   // every lane of the wave takes part in the swap
+                const int64_t i = pair_point(cb, lane);
+                if (i < end) take_point(xr, i, olds[u]);
+            }
+        }
+    } else {
+        for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)kKmThreads * U) {
+            double xs[U][D];
+            int32_t olds[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * kKmThreads;
+                if (i < end) {
+                    const double* p = P + i * D;
+                    if constexpr (D % 2 == 0) {
+#pragma unroll
+                        for (int c = 0; c < D; c += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(p + c);
+                            xs[u][c] = v.x;
+                            xs[u][c + 1] = v.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < D; ++c) xs[u][c] = p[c];
                     }
+                    olds[u] = labels[i];
                 }
             }
-            double dist = 0.0;
 #pragma unroll
-            for (int c = 0; c < D; ++c) {
-                const double df = x[c] - s_c[best * D + c];
-                dist += df * df;
-            }
-            acc[KMAX * D + KMAX] += dist;
-            if (mindist) mindist[i] = dist;
-            if (old != best) acc[KMAX * D + KMAX + 1] += 1.0;
-            labels[i] = best;
-#pragma unroll
-            for (int j = 0; j < KMAX; ++j) {
-                const bool mine = best == j;
-#pragma unroll
-                for (int c = 0; c < D; ++c) acc[j * D + c] += mine ? x[c] : 0.0;
-                acc[KMAX * D + j] += mine ? 1.0 : 0.0;
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * kKmThreads;
+                if (i >= end) break;
+                take_point(xs[u], i, olds[u]);
             }
         }
     }
@@ -411,7 +475,9 @@ __global__ __launch_bounds__(kKmThreads) void kmeanspp_update_kernel(const doubl
 // numpy: sqrt(add.reduce((x - c)**2, axis=1)); pairwise summation degenerates to a sequential
 // sum for d < 8 and to 8 interleaved partial sums for 8 <= d <= 128.
 __device__ __forceinline__ double np_norm(const double* x, const double* c, int d) {
-    // separately rounded multiply / add (no FMA contraction), as NumPy's ufunc loops do
+    // separately rounded multiply / add, as NumPy's ufunc loops do.  HIP's __dmul_rn / __dadd_rn are plain operators: without
+    // the pragma hipcc contracts df * df + res into one fma (seen in round 4: a returned distance one ulp off numpy's)
+#pragma clang fp contract(off)
     double sq[kKmMaxD];
 #pragma unroll
     for (int q = 0; q < kKmMaxD; ++q)
@@ -522,50 +588,74 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
     const int64_t per_block = (n + gridDim.x - 1) / gridDim.x;
     const int64_t begin = (int64_t)blockIdx.x * per_block;
     const int64_t end = begin + per_block < n ? begin + per_block : n;
-    for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)U * kKmThreads) {
-        double x[U][D];
+    // one point against the chunk's centroids
+    auto take_point = [&](const double (&xr)[D], int64_t i) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + (int64_t)u * kKmThreads;
-            const double* p = P + (i < end ? i : i0) * D;
-            if constexpr (D % 2 == 0) {
-#pragma unroll
-                for (int q = 0; q < D; q += 2) {
-                    const double2 v = *reinterpret_cast<const double2*>(p + q);
-                    x[u][q] = v.x;
-                    x[u][q + 1] = v.y;
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < D; ++q) x[u][q] = p[q];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t i = i0 + (int64_t)u * kKmThreads;
-            if (i >= end) break;
-#pragma unroll
-            for (int j = 0; j < KC; ++j) {
-                if (j < kc) {
-                    // np_norm for D < 8: sequentially added, separately rounded squares
-                    double res = 0.0;
+        for (int j = 0; j < KC; ++j) {
+            if (j < kc) {
+                // np_norm for D < 8: sequentially added, separately rounded squares (no fma contraction: see np_norm)
+                double res = 0.0;
+                {
+#pragma clang fp contract(off)
 #pragma unroll
                     for (int q = 0; q < D; ++q) {
-                        const double df = x[u][q] - s_c[j][q];
-                        res = __dadd_rn(res, __dmul_rn(df, df));
-                    }
-                    // numpy takes argmin over the ROUNDED distances sqrt(res): the first index wins among equal ones.  The
-                    // square root (a ~30-instruction float64 sequence, 120 M of them at 20M x 6: what bounded this pass) is
-                    // needed only where two sums of squares are so close that their roots could round to the same double:
-                    // below best * (1 - 2^-50) the rounded root is strictly smaller, at or above best it is not smaller.
-                    if (res < best[j]) {
-                        if (res < bthr[j] || __dsqrt_rn(res) < __dsqrt_rn(best[j])) {
-                            best[j] = res;
-                            bthr[j] = res * (1.0 - 0x1p-50);
-                            besti[j] = i;
-                        }
+                        const double df = xr[q] - s_c[j][q];
+                        const double sq = df * df;
+                        res = res + sq;
                     }
                 }
+                // numpy takes argmin over the ROUNDED distances sqrt(res): the first index wins among equal ones.  The
+                // square root (a ~30-instruction float64 sequence, 120 M of them at 20M x 6: what bounded this pass) is
+                // needed only where two sums of squares are so close that their roots could round to the same double:
+                // below best * (1 - 2^-50) the rounded root is strictly smaller, at or above best it is not smaller.
+                if (res < best[j]) {
+                    if (res < bthr[j] || __dsqrt_rn(res) < __dsqrt_rn(best[j])) {
+                        best[j] = res;
+                        bthr[j] = res * (1.0 - 0x1p-50);
+                        besti[j] = i;
+                    }
+                }
+            }
+        }
+    };
+    if constexpr (D == 4) {   // contiguous 16-byte units + pair swap (pair_issue / pair_finish above)
+        const int64_t nchunk = (end - begin + 63) / 64;
+        for (int64_t c0 = wave; c0 < nchunk; c0 += 4 * U) {
+            PairUnits pu[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) pair_issue(P, begin + (c0 + 4 * u) * 64, end, lane, pu[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                double xr[D];
+                pair_finish(pu[u], lane, xr);
+                const int64_t i = pair_point(begin + (c0 + 4 * u) * 64, lane);
+                if (i < end) take_point(xr, i);
+            }
+        }
+    } else {
+        for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)U * kKmThreads) {
+            double x[U][D];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * kKmThreads;
+                const double* p = P + (i < end ? i : i0) * D;
+                if constexpr (D % 2 == 0) {
+#pragma unroll
+                    for (int q = 0; q < D; q += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(p + q);
+                        x[u][q] = v.x;
+                        x[u][q + 1] = v.y;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < D; ++q) x[u][q] = p[q];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = i0 + (int64_t)u * kKmThreads;
+                if (i >= end) break;
+                take_point(x[u], i);
             }
         }
     }

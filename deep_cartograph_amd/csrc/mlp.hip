@@ -1186,23 +1186,27 @@ static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t*
     const int64_t tiles = (out <= 32 ? 1 : cdiv(out, 128)) * (in <= 32 ? 1 : cdiv(in, 128));
     int64_t want = cdiv(2 * (int64_t)num_cus(), tiles);
     int64_t max_by_rows = cdiv(rows, 256);
-    if (want > max_by_rows) {
-        // row-limited (small batches).  When 64 x 64 tiles reach two workgroups per CU with a split count the rows allow,
-        // take them (pick_cfg<kTN> follows: fewer than one 128 x 128 workgroup per CU): measured on the 256 x 512 x 8202
-        // product, 16 chunks of 64 x 64 tiles 21.9 us against 29 chunks of 128 x 128 tiles 23.7 -- and 16 slabs instead of
-        // 29 to write and reduce; a multiple of 8 chunks lets the XCD map keep a chunk's rows in one L2.
-        const int64_t tiles_q = cdiv(out, 64) * cdiv(in, 64);
-        const int64_t want_q = cdiv(cdiv(2 * (int64_t)num_cus(), tiles_q), 8) * 8;
-        if (out > 32 && in > 32 && want_q <= max_by_rows) {
-            int64_t kc = cdiv(cdiv(rows, want_q), 32) * 32;
-            if (cdiv(rows, kc) % 8 != 0) kc = cdiv(rows, want_q);   // ragged chunk ends (the stage tail goes through registers)
-            if (tiles * cdiv(rows, kc) <= (int64_t)num_cus() / 2) {   // pick_cfg<kTN>'s condition for 64 x 64 tiles
-                *k_chunk = kc;
-                *splits = cdiv(rows, kc);
-                return;
-            }
+    // Small batches.  When 64 x 64 tiles reach two workgroups per CU with a split count the rows allow, take them
+    // (pick_cfg<kTN> follows: fewer than one 128 x 128 workgroup per CU): measured on the 256 x 512 x 8202 product, 16 chunks
+    // of 64 x 64 tiles 21.9 us against 29 chunks of 128 x 128 tiles 23.7 -- and 16 slabs instead of 29 to write and reduce; a
+    // multiple of 8 chunks lets the XCD map keep a chunk's rows in one L2.  Round 4: also when the rows would allow the
+    // 128 x 128 plan but the chunks stay short (<= 1024 rows: 16 384 rows of a gathered 8192-pair batch gave 64 slabs of
+    // 512 KB per step -- 32 MB written and re-read by the reduction, 11.4 us -- where 16 chunks of 64 x 64 tiles leave 8 MB).
+    static const bool q_wide = [] { const char* e = getenv("DCV_WGRAD_Q"); return !(e && e[0] == '0'); }();
+    const int64_t tiles_q = cdiv(out, 64) * cdiv(in, 64);
+    const int64_t want_q = cdiv(cdiv(2 * (int64_t)num_cus(), tiles_q), 8) * 8;
+    if (out > 32 && in > 32 && want_q <= max_by_rows) {
+        int64_t kc = cdiv(cdiv(rows, want_q), 32) * 32;
+        if (cdiv(rows, kc) % 8 != 0) kc = cdiv(rows, want_q);   // ragged chunk ends (the stage tail goes through registers)
+        if (tiles * cdiv(rows, kc) <= (int64_t)num_cus() / 2 &&   // pick_cfg<kTN>'s condition for 64 x 64 tiles
+            (want > max_by_rows || (q_wide && kc <= 1024))) {
+            *k_chunk = kc;
+            *splits = cdiv(rows, kc);
+            return;
         }
-        // otherwise a split count that is a multiple of 8 keeps tiles x splits on whole multiples of the CU count (33
+    }
+    if (want > max_by_rows) {
+        // row-limited: a split count that is a multiple of 8 keeps tiles x splits on whole multiples of the CU count (33
         // splits x 8 tiles = 264 workgroups cost 1.6 x of 256: the 8 extra share SIMDs with 8 others)
         want = max_by_rows >= 8 ? max_by_rows / 8 * 8 : max_by_rows;
     }

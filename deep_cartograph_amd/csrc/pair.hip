@@ -43,6 +43,12 @@ static int launch_pair_mode(const Operand& A1, const Operand& B1, int64_t M1, in
         return launch_pair_cfg<S, CfgQuarterT<S>, CfgQuarterT<S>>(A1, B1, M1, N1, K1, kc1, e1, A2, B2, M2, N2, K2, e2, tiles_m_out2, tw, s);
     if (c1 == kPickBig && c2 == kPickBig)
         return launch_pair_cfg<S, CfgBigT<S>, CfgBigT<S>>(A1, B1, M1, N1, K1, kc1, e1, A2, B2, M2, N2, K2, e2, tiles_m_out2, tw, s);
+    // mixed families (round 4): a gathered (shuffled) batch of 8192 pairs is 16 384 rows -- the weight gradient still takes
+    // 64 x 64 split-K tiles, the input gradient 64 x 128 row tiles: launched apart they were 12.8 + 13.7 us of the 152 us step
+    if (c1 == kPickQuarter && c2 == kPickHalfM)
+        return launch_pair_cfg<S, CfgQuarterT<S>, CfgHalfMT<S>>(A1, B1, M1, N1, K1, kc1, e1, A2, B2, M2, N2, K2, e2, tiles_m_out2, tw, s);
+    if (c1 == kPickBig && c2 == kPickHalfM)
+        return launch_pair_cfg<S, CfgBigT<S>, CfgHalfMT<S>>(A1, B1, M1, N1, K1, kc1, e1, A2, B2, M2, N2, K2, e2, tiles_m_out2, tw, s);
     return 1;
 }
 

@@ -41,6 +41,7 @@ struct SnetDtArgs {
     int64_t ld;
     RowMap rows;                  // half = batch: logical row p < B is x_t of pair p, row B + p its x_lag
     int B;                        // pairs of this rank's batch
+    int d;                        // network outputs (<= 4)
     int store_blob;
     float* blob;                  // [workgroups][blob_stride]
     int64_t blob_stride;
@@ -61,14 +62,23 @@ __device__ __forceinline__ unsigned touch_kernargs() {
     return x;
 }
 
-template <int TR, int D>
+union TicaWaveLdsAny {
+    TicaWaveLds<1> h1;
+    TicaWaveLds<2> h2;
+    TicaWaveLds<3> h3;
+    TicaWaveLds<4> h4;
+};
+// TR rows per workgroup = TR / 2 pairs (32, 64 or 128: larger tiles mean fewer statistics / gradient partials for the
+// ticketed sums and the reduction launch behind; the work of a tile is latency, not arithmetic, at these widths)
+template <int TR>
 __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a) {
     constexpr int NT = kSnetThreads, HP = TR / 2;
     constexpr int RG = TR / 16, CG = kSnetWaves / RG;
-    constexpr int W = 2 * D + 2 * D * D;
+    constexpr int XU = TR / 8;   // 16-byte units of the input tile per thread (TR * pin / 4 <= XU * NT: pin <= 256 * 32 / TR ... checked by the plan)
+    const int D = a.d, W = 2 * D + 2 * D * D;
     extern __shared__ __attribute__((aligned(16))) float sl[];
-    __shared__ TicaWaveLds<D> s_head;
-    __shared__ double s_stat[W];
+    __shared__ TicaWaveLdsAny s_head;
+    __shared__ double s_stat[40];
     __shared__ unsigned s_flag;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rg = wave % RG, cg = wave / RG;
@@ -86,19 +96,26 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
         const int64_t p = p0 + (r - half * HP);
         return p < a.B ? a.rows.template get<true>(half ? (int64_t)a.B + p : p) : -1;
     };
-    float4 xv[4];
+    constexpr int XA = XU < 8 ? XU : 8;   // units that ride along the weight staging; the rest (TR = 128) in a second batch
+    float4 xv[XA];
     bool x_issued = false;
-    auto issue_x = [&]() {
+    auto load_x = [&](int u) -> float4 {
         const int f4 = F0 >> 2;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
-            xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < x_tot && c < f4) {
-                const int64_t row = src_row(r);
-                if (row >= 0) xv[u] = *reinterpret_cast<const float4*>(a.Xn + row * a.ld + 4 * c);
-            }
+        const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < x_tot && c < f4) {
+            const int64_t row = src_row(r);
+            if (row >= 0) v = *reinterpret_cast<const float4*>(a.Xn + row * a.ld + 4 * c);
         }
+        return v;
+    };
+    auto store_x = [&](int u, const float4& v) {
+        const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
+        if (i < x_tot) *reinterpret_cast<float4*>(H0 + r * ps0 + 4 * c) = v;
+    };
+    auto issue_x = [&]() {
+#pragma unroll
+        for (int u = 0; u < XA; ++u) xv[u] = load_x(u);
     };
     // ---- stage every weight image and bias (snet.hip: one flat table, twelve loads in flight, two dependent round trips)
     for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
@@ -137,9 +154,13 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
     asm volatile("" ::"s"(ka_touch));
     if (x_vec) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
-            if (i < x_tot) *reinterpret_cast<float4*>(H0 + r * ps0 + 4 * c) = xv[u];
+        for (int u = 0; u < XA; ++u) store_x(u, xv[u]);
+        if constexpr (XU > XA) {
+            float4 xw[XU - XA];
+#pragma unroll
+            for (int u = XA; u < XU; ++u) xw[u - XA] = load_x(u);
+#pragma unroll
+            for (int u = XA; u < XU; ++u) store_x(u, xw[u - XA]);
         }
     } else {
         for (int i = t; i < TR * pin0; i += NT) {
@@ -210,7 +231,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
     // ---- last workgroup: the partials in block order, then the d x d loss head
     if (!handoff_arrive_last(a.ticket, gridDim.x, &s_flag)) return;
     {
-        constexpr int G = NT / W;
+        const int G = NT / W;
         double* s_grp = reinterpret_cast<double*>(sl);   // [G][W]: the weight images are dead
         const int g = t / W, o = t - g * W;
         if (g < G) {
@@ -231,27 +252,32 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
         __syncthreads();
         if (t < W) {
             double s = 0.0;
-#pragma unroll
             for (int g2 = 0; g2 < G; ++g2) s += s_grp[g2 * W + t];
             a.stats[t] = s;
             s_stat[t] = s;
         }
         if (a.fused.on) {
             __syncthreads();
-            if (wave == 0)
-                tica_grad_wave<D>(s_head, s_stat, a.fused.Bg, a.fused.reg, a.fused.gradp, a.fused.log, a.fused.log_count, a.fused.log_cap,
-                                  a.fused.log_width, lane);
+            if (wave == 0) {
+                const FusedHead& f = a.fused;
+                switch (D) {
+                    case 1: tica_grad_wave<1>(s_head.h1, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
+                    case 2: tica_grad_wave<2>(s_head.h2, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
+                    case 3: tica_grad_wave<3>(s_head.h3, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
+                    default: tica_grad_wave<4>(s_head.h4, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
+                }
+            }
         }
     }
 }
 
-template <int TR, int D>
+template <int TR>
 __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a) {
     constexpr int NT = kSnetThreads, HP = TR / 2;
     constexpr int RG = TR / 16, CG = kSnetWaves / RG;
-    constexpr int NG = 2 * D + 2 * D * D;   // mu | Gu | Gv | c
+    const int D = a.d, NG = 2 * D + 2 * D * D;   // mu | Gu | Gv | c
     extern __shared__ __attribute__((aligned(16))) float sl[];
-    __shared__ double s_g[NG];
+    __shared__ double s_g[40];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rg = wave % RG, cg = wave / RG;
     const int q = lane >> 4, n = lane & 15;
@@ -337,11 +363,11 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
         const int pl = t / D, i = t - pl * D;
         const bool mine = t < HP * D;
         const bool valid = mine && p0 + pl < a.B;
-        float ft[D], fg[D];
+        float ft[4], fg[4];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            ft[k] = mine ? FL[pl * psL + k] : 0.f;
-            fg[k] = mine ? FL[(HP + pl) * psL + k] : 0.f;
+        for (int k = 0; k < 4; ++k) {
+            ft[k] = (mine && k < D) ? FL[pl * psL + k] : 0.f;
+            fg[k] = (mine && k < D) ? FL[(HP + pl) * psL + k] : 0.f;
         }
         __syncthreads();   // every thread has read its pair before any value is overwritten
         if (mine) {
@@ -353,15 +379,17 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
                 const double* cv = Gv + D * D;
                 double g1 = cv[i], g2 = 0.0;
 #pragma unroll
-                for (int k = 0; k < D; ++k) {
-                    const double u = (double)ft[k] - mu[k], v = (double)fg[k] - mu[k];
-                    g1 = fma(Gu[i * D + k], u, g1);
-                    g1 = fma(Gv[i * D + k], v, g1);
-                    g2 = fma(Gv[i * D + k], u, g2);
+                for (int k = 0; k < 4; ++k) {
+                    if (k < D) {
+                        const double u = (double)ft[k] - mu[k], v = (double)fg[k] - mu[k];
+                        g1 = fma(Gu[i * D + k], u, g1);
+                        g1 = fma(Gv[i * D + k], v, g1);
+                        g2 = fma(Gv[i * D + k], u, g2);
+                    }
                 }
                 float fti = ft[0], fgi = fg[0];   // ft[i] / fg[i] without a dynamically indexed register array
 #pragma unroll
-                for (int k = 1; k < D; ++k) {
+                for (int k = 1; k < 4; ++k) {
                     fti = i == k ? ft[k] : fti;
                     fgi = i == k ? fg[k] : fgi;
                 }
@@ -449,9 +477,8 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
 }
 
 struct SnetDtPlan {
-    int TR;
-    size_t lds_bytes;
-    SnetDtArgs base;
+    SnetDtArgs base;       // layer table, staging table; the activation map is laid out per launch (it depends on TR)
+    int fl;                // LDS floats of the weight images
     int64_t per_wg;        // floats of one workgroup's gradient partials (dense)
     int2* stage_tab;
     float* part;           // gradient partials
@@ -460,8 +487,47 @@ struct SnetDtPlan {
     int64_t blob_floats;
     double* spart;         // statistics partials
     int64_t spart_n;
-    int64_t last_wg;       // workgroups of the last forward (the backward launches the same grid)
+    int64_t last_wg;       // workgroups and tile rows of the last forward (the backward launches the same grid)
+    int last_tr;
 };
+constexpr size_t kSnetDtLdsMax = 160 * 1024 - 8 * 1024;   // static LDS of the kernels (loss head, flags) and a margin
+
+// activation map of a TR-row tile behind the weight images; returns the LDS floats needed
+static int snet_dt_map(SnetDtArgs& a, int fl, int TR) {
+    int f = fl;
+    for (int l = 0; l <= a.L; ++l) {
+        const int P = l == 0 ? a.l[0].pin : a.l[l - 1].pout;
+        a.ps[l] = P + 4;
+        a.lh[l] = f;
+        f += TR * (P + 4);
+    }
+    a.act_len = f - a.lh[0];
+    return f < 2048 ? 2048 : f;   // the last arriver sums the statistics partials in the first 4 KB
+}
+// rows per tile for a batch of B pairs: the smallest tile that keeps the launch at <= 128 workgroups (the ticketed partial
+// sums and the gradient reduction walk one partial per workgroup), provided the tile fits: TR * pin / 4 <= (TR / 8) * 512
+// input units per thread (pin <= 64 * 32 / TR ... i.e. always for pin <= 256 at TR = 32, pin <= 256 at 64 and 128 too since
+// the unit count per thread grows with TR) and the activation map fits in LDS
+static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
+    static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();
+    int best = 0;
+    for (int TR : {32, 64, 128}) {
+        SnetDtArgs tmp = pl->base;
+        if ((size_t)snet_dt_map(tmp, pl->fl, TR) * sizeof(float) > kSnetDtLdsMax) break;
+        // the backward keeps a layer's input-gradient tiles of a wave in registers: kSnetMaxTiles * (8 waves / (TR / 16) row groups)
+        // column tiles of 16 must cover the widest hidden layer
+        bool fits = true;
+        for (int l = 1; l < tmp.L; ++l) fits = fits && tmp.l[l].nk_in <= kSnetMaxTiles * (kSnetWaves / (TR / 16));
+        if (!fits) break;
+        if (tr_env != 0) {
+            if (tr_env == TR) return TR;
+            continue;
+        }
+        best = TR;
+        if (cdiv(B, TR / 2) <= 128) break;
+    }
+    return best;
+}
 
 static bool snet_dt_build(dcv_mlp* m) {
     if (m->desc.model != DCV_MODEL_DEEPTICA || m->any_drop || m->any_bn || m->d_out > 4 || m->d_out < 1 || snet_disabled()) return false;
@@ -470,12 +536,18 @@ static bool snet_dt_build(dcv_mlp* m) {
     *pl = SnetDtPlan{};
     SnetDtArgs& a = pl->base;
     a.L = m->L;
+    a.d = m->d_out;
     int fl = 0;
     int64_t per_wg = 0;
     std::vector<int2> tab;
     int tab_begin[DCV_MAX_LAYERS];
     if (!snet_layout(m, a.l, tab, tab_begin, fl, per_wg)) { delete pl; return false; }
     pl->per_wg = per_wg;
+    pl->fl = fl;
+    {
+        SnetDtArgs tmp = a;
+        if ((size_t)snet_dt_map(tmp, fl, 32) * sizeof(float) > kSnetDtLdsMax) { delete pl; return false; }
+    }
     if (hipMalloc(reinterpret_cast<void**>(&pl->stage_tab), tab.size() * sizeof(int2)) != hipSuccess ||
         hipMemcpy(pl->stage_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipGetLastError();
@@ -486,24 +558,6 @@ static bool snet_dt_build(dcv_mlp* m) {
     a.stage_tab = pl->stage_tab;
     a.stage_n = (int)tab.size();
     a.stage_bwd0 = m->L > 1 ? tab_begin[1] : (int)tab.size();
-    const size_t lds_max = 160 * 1024 - 8 * 1024;   // static LDS of the kernels (loss head, flags) and a margin
-    const int TR = 32;
-    int f = fl;
-    for (int l = 0; l <= m->L; ++l) {
-        const int P = l == 0 ? a.l[0].pin : a.l[l - 1].pout;
-        a.ps[l] = P + 4;
-        a.lh[l] = f;
-        f += TR * (P + 4);
-    }
-    a.act_len = f - a.lh[0];
-    if (f < 2048) f = 2048;   // the last arriver sums the statistics partials in the first 4 KB
-    if ((size_t)f * sizeof(float) > lds_max) {
-        (void)hipFree(pl->stage_tab);
-        delete pl;
-        return false;
-    }
-    pl->TR = TR;
-    pl->lds_bytes = (size_t)f * sizeof(float);
     m->snet_dt = pl;
     return true;
 }
@@ -534,10 +588,10 @@ static bool grow(T** p, int64_t* have, int64_t need) {
 }
 
 template <class K>
-static int snet_dt_launch(K kern, int slot, const SnetDtPlan* pl, const SnetDtArgs& a, int64_t nwg, hipStream_t s) {
+static int snet_dt_launch(K kern, int slot, size_t lds_bytes, const SnetDtArgs& a, int64_t nwg, hipStream_t s) {
     static int attr_state[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // per kernel instantiation: 0 unknown, 1 set, -1 refused by the runtime
     if (attr_state[slot] == 0) {
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024);
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSnetDtLdsMax);
         if (e != hipSuccess) (void)hipGetLastError();
         attr_state[slot] = e == hipSuccess ? 1 : -1;
     }
@@ -546,9 +600,9 @@ static int snet_dt_launch(K kern, int slot, const SnetDtPlan* pl, const SnetDtAr
         const LaunchEvents ev = g_launch_ev;
         g_launch_ev = LaunchEvents{};
         g_launch_taken = ev.start;
-        hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), (uint32_t)pl->lds_bytes, s, ev.start, ev.stop, 0u, a);
+        hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), (uint32_t)lds_bytes, s, ev.start, ev.stop, 0u, a);
     } else {
-        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), pl->lds_bytes, s, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), lds_bytes, s, a);
     }
     DCV_CHECK_LAUNCH();
     return DCV_OK;
@@ -568,13 +622,15 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
         m->snet_dt_tried = true;
     }
     SnetDtPlan* pl = static_cast<SnetDtPlan*>(m->snet_dt);
-    const int HP = pl->TR / 2;
-    const int64_t nwg = cdiv(batch, HP);
-    const int W = m->stats_len;
-    if (nwg > 512 || nwg * pl->per_wg * (int64_t)sizeof(float) > kMaxBytes || nwg * pl->base.act_len * (int64_t)sizeof(float) > kMaxBytes) return 1;
-    if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
-    if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)pl->base.act_len)) return 1;
+    const int TR = snet_dt_pick_tr(pl, batch);
+    if (TR == 0) return 1;
     SnetDtArgs a = pl->base;
+    const size_t lds_bytes = (size_t)snet_dt_map(a, pl->fl, TR) * sizeof(float);
+    const int64_t nwg = cdiv(batch, TR / 2);
+    const int W = m->stats_len;
+    if (nwg > 512 || nwg * pl->per_wg * (int64_t)sizeof(float) > kMaxBytes || nwg * a.act_len * (int64_t)sizeof(float) > kMaxBytes) return 1;
+    if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
+    if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)a.act_len)) return 1;
     a.params = m->params;
     a.Xn = Xn_d;
     a.ld = ld;
@@ -591,11 +647,11 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     a.gradp = nullptr;
     a.part = nullptr;
     pl->last_wg = nwg;
-    switch (m->d_out) {
-        case 1: return snet_dt_launch(snet_dt_fwd_kernel<32, 1>, 0, pl, a, nwg, s);
-        case 2: return snet_dt_launch(snet_dt_fwd_kernel<32, 2>, 1, pl, a, nwg, s);
-        case 3: return snet_dt_launch(snet_dt_fwd_kernel<32, 3>, 2, pl, a, nwg, s);
-        default: return snet_dt_launch(snet_dt_fwd_kernel<32, 4>, 3, pl, a, nwg, s);
+    pl->last_tr = TR;
+    switch (TR) {
+        case 32: return snet_dt_launch(snet_dt_fwd_kernel<32>, 0, lds_bytes, a, nwg, s);
+        case 64: return snet_dt_launch(snet_dt_fwd_kernel<64>, 1, lds_bytes, a, nwg, s);
+        default: return snet_dt_launch(snet_dt_fwd_kernel<128>, 2, lds_bytes, a, nwg, s);
     }
 }
 
@@ -607,7 +663,8 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t 
         set_error("snet_dt_backward: no fused forward to go back through");
         return DCV_ESTATE;
     }
-    const int64_t nwg = cdiv(batch, pl->TR / 2);
+    const int TR = pl->last_tr;
+    const int64_t nwg = cdiv(batch, TR / 2);
     if (nwg != pl->last_wg) {
         set_error("snet_dt_backward: batch=%d does not match the fused forward", batch);
         return DCV_ESTATE;
@@ -618,6 +675,7 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t 
         return DCV_ENOMEM;
     }
     SnetDtArgs a = pl->base;
+    const size_t lds_bytes = (size_t)snet_dt_map(a, pl->fl, TR) * sizeof(float);
     int64_t off = 0;
     for (int l = 0; l < m->L; ++l) {
         SnetLayer& y = a.l[l];
@@ -634,11 +692,10 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t 
     a.blob_stride = a.act_len;
     a.gradp = m->gradp;
     a.part = pl->part;
-    switch (m->d_out) {
-        case 1: return snet_dt_launch(snet_dt_bwd_kernel<32, 1>, 4, pl, a, nwg, s);
-        case 2: return snet_dt_launch(snet_dt_bwd_kernel<32, 2>, 5, pl, a, nwg, s);
-        case 3: return snet_dt_launch(snet_dt_bwd_kernel<32, 3>, 6, pl, a, nwg, s);
-        default: return snet_dt_launch(snet_dt_bwd_kernel<32, 4>, 7, pl, a, nwg, s);
+    switch (TR) {
+        case 32: return snet_dt_launch(snet_dt_bwd_kernel<32>, 4, lds_bytes, a, nwg, s);
+        case 64: return snet_dt_launch(snet_dt_bwd_kernel<64>, 5, lds_bytes, a, nwg, s);
+        default: return snet_dt_launch(snet_dt_bwd_kernel<128>, 6, lds_bytes, a, nwg, s);
     }
 }
 

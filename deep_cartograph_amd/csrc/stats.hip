@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void normalize_kernel(const float* __restrict_
 // The same for rows of F = 4 * ng floats with 256 % ng == 0: a thread keeps ONE column group -- mean and range are read
 // once -- and walks the block's rows with U independent 16-byte loads in flight (the flat grid-stride form above has one
 // load in flight per thread, a 64-bit division per element and re-reads mean / range every iteration: 4.5 TB/s at 5M x 256).
-template <int U>
+// NT (DCV_NORMALIZE_NT=1, experiment): the matrix is streamed once -- non-temporal loads / stores keep it out of the L2's way
+template <int U, bool NT = false>
 __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __restrict__ X, float* __restrict__ Y, int64_t n, int ng,
                                                              int64_t ldx, int64_t ldy, const float* __restrict__ mean,
                                                              const float* __restrict__ range, int rows_per_block) {
@@ -225,7 +226,13 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t rr = r + (int64_t)u * lanes;
-            x[u] = rr < r1 ? *reinterpret_cast<const float4*>(X + rr * ldx + 4 * tx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (NT) {
+                typedef float nv4 __attribute__((ext_vector_type(4)));
+                const nv4 v = rr < r1 ? __builtin_nontemporal_load(reinterpret_cast<const nv4*>(X + rr * ldx + 4 * tx)) : nv4{0.f, 0.f, 0.f, 0.f};
+                x[u] = make_float4(v.x, v.y, v.z, v.w);
+            } else {
+                x[u] = rr < r1 ? *reinterpret_cast<const float4*>(X + rr * ldx + 4 * tx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -236,7 +243,12 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
                 y.y = __fdiv_rn(__fsub_rn(x[u].y, m.y), s.y);
                 y.z = __fdiv_rn(__fsub_rn(x[u].z, m.z), s.z);
                 y.w = __fdiv_rn(__fsub_rn(x[u].w, m.w), s.w);
-                *reinterpret_cast<float4*>(Y + rr * ldy + 4 * tx) = y;
+                if constexpr (NT) {
+                    typedef float nv4 __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(nv4{y.x, y.y, y.z, y.w}, reinterpret_cast<nv4*>(Y + rr * ldy + 4 * tx));
+                } else {
+                    *reinterpret_cast<float4*>(Y + rr * ldy + 4 * tx) = y;
+                }
             }
         }
     }
@@ -293,7 +305,11 @@ extern "C" int dcv_normalize(const float* X_d, float* Y_d, int64_t n, int32_t F,
         const int lanes = 256 / ng;
         int rpb = lanes * 8 * 4;   // four rounds of eight loads per thread
         while ((int64_t)cdiv(n, rpb) > (int64_t)num_cus() * 64) rpb *= 2;
-        hipLaunchKernelGGL(normalize_rows_kernel<8>, dim3((unsigned)cdiv(n, rpb)), dim3(256), 0, s, X_d, Y_d, n, ng, ldx, ldy, mean_d, range_d, rpb);
+        static const int nt_env = [] { const char* e = getenv("DCV_NORMALIZE_NT"); return e ? atoi(e) : 0; }();
+        static const int rpb_env = [] { const char* e = getenv("DCV_NORMALIZE_RPB"); return e ? atoi(e) : 0; }();
+        if (rpb_env > 0) rpb = rpb_env;
+        if (nt_env) hipLaunchKernelGGL((normalize_rows_kernel<8, true>), dim3((unsigned)cdiv(n, rpb)), dim3(256), 0, s, X_d, Y_d, n, ng, ldx, ldy, mean_d, range_d, rpb);
+        else hipLaunchKernelGGL((normalize_rows_kernel<8, false>), dim3((unsigned)cdiv(n, rpb)), dim3(256), 0, s, X_d, Y_d, n, ng, ldx, ldy, mean_d, range_d, rpb);
     } else if (v4)
         hipLaunchKernelGGL(normalize_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, s, X_d, Y_d, n, F, ldx, ldy, mean_d,
                            range_d);

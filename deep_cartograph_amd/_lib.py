@@ -44,6 +44,7 @@ class MlpDesc(C.Structure):
         ("batchnorm", C.c_int32 * DCV_MAX_LAYERS),
         ("bn_eps", C.c_double),
         ("bn_momentum", C.c_double),
+        ("maximize", C.c_int32),
     ]
 
 
@@ -153,8 +154,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.dcv_abi_version()
-    if ver != 3:
-        raise DcvError(f"libdcv.so ABI version {ver}, expected 3 (rebuild: make -C deep_cartograph_amd/csrc)")
+    if ver != 4:
+        raise DcvError(f"libdcv.so ABI version {ver}, expected 4 (rebuild: make -C deep_cartograph_amd/csrc)")
     _lib = lib
     return lib
 

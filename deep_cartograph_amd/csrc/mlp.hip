@@ -88,6 +88,7 @@ struct OptArgs {
     float w1, w2;     // 1 - beta1 (Adam) / 1 - dampening (SGD) ; 1 - beta2 (Adam) / 1 - alpha (RMSprop)
     float decay;      // AdamW: 1 - lr * weight_decay
     float p0, p1, p2, p3;   // further per-step scalars of Adamax / NAdam / RAdam / Adadelta / ASGD / Rprop (next_opt_args)
+    int maximize;           // torch.optim's maximize: the update runs on the negated gradient
 };
 // pi = p[i], loaded by the caller (the reduction kernels issue that load before they wait for the partial sums)
 // WT: write-through stores (the launch then ends without dirty lines to write back: reduce_grads_quad_kernel)
@@ -99,6 +100,7 @@ __device__ __forceinline__ void opt_st(float* p, float v) {
 template <bool WT = false>
 __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
                                              float* __restrict__ s3, const OptArgs& a) {
+    if (a.maximize) gi = -gi;   // `grad = grads[i] if not maximize else -grads[i]`: the first line of every _single_tensor_* update
     switch (a.kind) {
         case DCV_OPT_ADAM:
         case DCV_OPT_ADAMW: {
@@ -1189,10 +1191,12 @@ static void wgrad_plan(int out, int in, int64_t rows, int64_t* k_chunk, int64_t*
     // Small batches.  When 64 x 64 tiles reach two workgroups per CU with a split count the rows allow, take them
     // (pick_cfg<kTN> follows: fewer than one 128 x 128 workgroup per CU): measured on the 256 x 512 x 8202 product, 16 chunks
     // of 64 x 64 tiles 21.9 us against 29 chunks of 128 x 128 tiles 23.7 -- and 16 slabs instead of 29 to write and reduce; a
-    // multiple of 8 chunks lets the XCD map keep a chunk's rows in one L2.  Round 4: also when the rows would allow the
-    // 128 x 128 plan but the chunks stay short (<= 1024 rows: 16 384 rows of a gathered 8192-pair batch gave 64 slabs of
-    // 512 KB per step -- 32 MB written and re-read by the reduction, 11.4 us -- where 16 chunks of 64 x 64 tiles leave 8 MB).
-    static const bool q_wide = [] { const char* e = getenv("DCV_WGRAD_Q"); return !(e && e[0] == '0'); }();
+    // multiple of 8 chunks lets the XCD map keep a chunk's rows in one L2.  Round 4 tried the same plan where the rows would
+    // allow the 128 x 128 one but the chunks stay short (<= 1024 rows: the 16 384 rows of a gathered 8192-pair batch give 64
+    // slabs of 512 KB per step -- 32 MB written and re-read by the reduction, 11.4 us -- where 16 chunks of 64 x 64 tiles leave
+    // 8 MB): the reduction fell to 7.0 us, but the GATHERED weight gradient went from 38.7 to 60.0 us (per-thread 64-bit row
+    // pointers: four times the stage loads per flop of the 128 x 128 tile) -- kept behind DCV_WGRAD_Q=1, off by default.
+    static const bool q_wide = [] { const char* e = getenv("DCV_WGRAD_Q"); return e && e[0] == '1'; }();   // opt-in: see below
     const int64_t tiles_q = cdiv(out, 64) * cdiv(in, 64);
     const int64_t want_q = cdiv(cdiv(2 * (int64_t)num_cus(), tiles_q), 8) * 8;
     if (out > 32 && in > 32 && want_q <= max_by_rows) {
@@ -1806,14 +1810,16 @@ static int forward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t
         // a network that fits in LDS: forward, batch statistics and (one-GPU steps) the loss head in ONE launch (snet_dt.hip)
         if (fuse_head) DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp step: call dcv_mlp_reset_log first");
         prof_mark(m, 0, 0, 0, s);
-        const int rcs = snet_dt_forward(m, Xn_d, ld, idx_d, row0, batch, fuse_head, fuse_head != 2, s);
+        // the loss head runs inside the forward launch only when no backward follows (evaluation step); a training step's
+        // head is evaluated by the backward launch's workgroups beside their staging (snet_dt.hip)
+        const int rcs = snet_dt_forward(m, Xn_d, ld, idx_d, row0, batch, fuse_head == 2 ? 2 : 0, fuse_head != 2, s);
         if (rcs < 0) return rcs;
         if (rcs == DCV_OK) {
             prof_mark(m, 0, 0, 1, s);
             m->snet_fwd_valid = fuse_head != 2;
             m->last_path = 2;
             m->last_batch = batch;
-            m->head_done = fuse_head != 0;
+            m->head_done = fuse_head == 2;
             return DCV_OK;
         }
         if (prof_on(m, 0)) g_launch_ev = LaunchEvents{};   // not applicable: the layer-by-layer path marks its own launches
@@ -1970,7 +1976,8 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
     float* dz_nxt = m->dZ[1];
     bool fused_head = false;
     if (m->desc.model == DCV_MODEL_DEEPTICA) {
-        if (!m->head_done) {
+        const bool head_in_bwd = m->last_path == 2 && train && !m->head_done && m->snet_fwd_valid;   // the fused backward evaluates the head itself
+        if (!m->head_done && !head_in_bwd) {
             if (TicaGradWaveFn wf = tica_grad_wave_fn(m->d_out)) {
                 hipLaunchKernelGGL(wf, dim3(1), dim3(64), 0, s, (const double*)m->stats, (double)global_batch, m->desc.tica_reg,
                                    train ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width);
@@ -1990,7 +1997,7 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
             }
             ReduceArgsView v;
             prof_mark(m, 0, 1, 0, s);
-            int rcb = snet_dt_backward(m, batch, &v, s);
+            int rcb = snet_dt_backward(m, batch, global_batch, head_in_bwd, &v, s);
             if (rcb) return rcb;
             prof_mark(m, 0, 1, 1, s);
             ReduceArgs raf{};
@@ -2253,6 +2260,7 @@ static OptArgs next_opt_args(dcv_mlp* m) {
     a.decay = 1.f;
     a.eps = (float)d.eps;
     a.wd = (float)d.weight_decay;
+    a.maximize = d.maximize ? 1 : 0;
     switch (d.optimizer) {
         case DCV_OPT_ADAM:
         case DCV_OPT_ADAMW: {

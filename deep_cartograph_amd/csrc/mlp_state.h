@@ -110,7 +110,7 @@ void snet_free(dcv_mlp* m);
 // snet_dt.hip: Deep-TICA forward (+ statistics, + loss head) and backward of a network that fits in LDS; 1 = not applicable
 int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
                     hipStream_t s);
-int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t s);
+int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s);
 void snet_dt_free(dcv_mlp* m);
 // bn.hip
 int bn_forward(dcv_mlp* m, int l, int64_t row0, int64_t rows, bool train, hipStream_t s);

@@ -278,6 +278,8 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
     const int D = a.d, NG = 2 * D + 2 * D * D;   // mu | Gu | Gv | c
     extern __shared__ __attribute__((aligned(16))) float sl[];
     __shared__ double s_g[40];
+    __shared__ double s_stat[40];
+    __shared__ TicaWaveLdsAny s_head;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rg = wave % RG, cg = wave / RG;
     const int q = lane >> 4, n = lane & 15;
@@ -297,6 +299,29 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
         for (int u = 0; u < 8; ++u) {
             const int i = t + NT * u;
             bv[u] = i < n4 ? *reinterpret_cast<const float4*>(bsrc + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // The d x d loss head HERE, by the last wave of every workgroup, from the batch statistics the forward launch left
+    // (all-reduced in between in a data-parallel step): ~3 us of dependent float64 algebra that sat on the forward launch's
+    // critical path (its last arriver, the whole chip waiting) now runs while this wave's staging loads are in flight and
+    // the other waves stage theirs.  Every workgroup computes the same matrices (deterministic: same inputs, same code);
+    // the first one appends the loss record.
+    bool head_ran = false;
+    auto run_head = [&]() {
+        head_ran = true;
+        if (!a.fused.on) return;
+        if (wave == kSnetWaves - 1) {
+            if (lane < NG) s_stat[lane] = a.stats[lane];
+            wave_sync_lds();
+            const FusedHead& f = a.fused;
+            double* logp = blockIdx.x == 0 ? f.log : nullptr;
+            int* lc = blockIdx.x == 0 ? f.log_count : nullptr;
+            switch (D) {
+                case 1: tica_grad_wave<1>(s_head.h1, s_stat, f.Bg, f.reg, s_g, logp, lc, f.log_cap, f.log_width, lane); break;
+                case 2: tica_grad_wave<2>(s_head.h2, s_stat, f.Bg, f.reg, s_g, logp, lc, f.log_cap, f.log_width, lane); break;
+                case 3: tica_grad_wave<3>(s_head.h3, s_stat, f.Bg, f.reg, s_g, logp, lc, f.log_cap, f.log_width, lane); break;
+                default: tica_grad_wave<4>(s_head.h4, s_stat, f.Bg, f.reg, s_g, logp, lc, f.log_cap, f.log_width, lane); break;
+            }
         }
     };
     for (int i0 = a.stage_bwd0 + t; i0 < a.stage_n; i0 += 12 * NT) {
@@ -327,12 +352,14 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
                 }
             }
         }
+        if (!head_ran) run_head();   // this wave's table, blob and data loads are in flight
 #pragma unroll
         for (int u = 0; u < 12; ++u)
             if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
     }
     if (!blob_issued) issue_blob();
-    if (t < NG) s_g[t] = a.gradp[t];
+    if (!head_ran) run_head();
+    if (!a.fused.on && t < NG) s_g[t] = a.gradp[t];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
         const int i = t + NT * u;
@@ -504,8 +531,8 @@ static int snet_dt_map(SnetDtArgs& a, int fl, int TR) {
     a.act_len = f - a.lh[0];
     return f < 2048 ? 2048 : f;   // the last arriver sums the statistics partials in the first 4 KB
 }
-// rows per tile for a batch of B pairs: the smallest tile that keeps the launch at <= 128 workgroups (the ticketed partial
-// sums and the gradient reduction walk one partial per workgroup), provided the tile fits: TR * pin / 4 <= (TR / 8) * 512
+// rows per tile for a batch of B pairs: the smallest tile that keeps the launch at <= 256 workgroups (one per CU; the ticketed
+// partial sums and the gradient reduction walk one partial per workgroup), provided the tile fits: TR * pin / 4 <= (TR / 8) * 512
 // input units per thread (pin <= 64 * 32 / TR ... i.e. always for pin <= 256 at TR = 32, pin <= 256 at 64 and 128 too since
 // the unit count per thread grows with TR) and the activation map fits in LDS
 static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
@@ -524,7 +551,7 @@ static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
             continue;
         }
         best = TR;
-        if (cdiv(B, TR / 2) <= 128) break;
+        if (cdiv(B, TR / 2) <= 256) break;   // one round of the chip; measured at 4096 pairs: 128 tiles of 64 rows 41.8 us / step, 256 of 32 rows 38.2
     }
     return best;
 }
@@ -656,8 +683,9 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
 }
 
 // Fused backward of the batch whose forward snet_dt_forward ran last (its blob is in place): gradient partials for the
-// reduction, whose descriptors go to `ra`.  m->gradp holds the loss head's matrices.
-int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t s) {
+// reduction, whose descriptors go to `ra`.  head: the loss head has not run yet -- every workgroup evaluates it from m->stats
+// (the sums over the GLOBAL batch) and the first one appends the loss record; otherwise m->gradp holds the head's matrices.
+int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s) {
     SnetDtPlan* pl = static_cast<SnetDtPlan*>(m->snet_dt);
     if (!pl || !pl->blob) {
         set_error("snet_dt_backward: no fused forward to go back through");
@@ -692,6 +720,9 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, ReduceArgsView* ra, hipStream_t 
     a.blob_stride = a.act_len;
     a.gradp = m->gradp;
     a.part = pl->part;
+    a.stats = m->stats;
+    a.fused = FusedHead{0, 0.0, 0.0, nullptr, nullptr, nullptr, 0, 0};
+    if (head) a.fused = FusedHead{1, (double)global_batch, m->desc.tica_reg, nullptr, m->log, m->log_count, m->log_cap, m->log_width};
     switch (TR) {
         case 32: return snet_dt_launch(snet_dt_bwd_kernel<32>, 4, lds_bytes, a, nwg, s);
         case 64: return snet_dt_launch(snet_dt_bwd_kernel<64>, 5, lds_bytes, a, nwg, s);

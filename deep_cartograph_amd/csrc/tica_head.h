@@ -121,6 +121,7 @@ __device__ __forceinline__ void tica_grad_wave(TicaWaveLds<D>& w, const double* 
         for (int m = 0; m < D; ++m) cs += -(w.T[lane * D + m] + w.T[m * D + lane]) * (w.ml[m] - w.mu[m]);
         gradp[D + 2 * D * D + lane] = -cs * invB;
     }
+    if (log_count == nullptr) return;   // no record asked for (the workgroups of a fused backward other than the first)
     const int slot = *log_count;
     if (slot < log_cap) {
         double* rec = log + (int64_t)slot * log_width;

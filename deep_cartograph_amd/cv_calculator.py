@@ -754,9 +754,8 @@ class NonLinear(CVCalculator):
         for k, v in (self.optimizer_config.get("kwargs", {}) or {}).items():
             if k in _IMPLEMENTATION_SWITCHES:
                 continue
-            if k == "maximize":
-                if v:
-                    raise NotImplementedError("maximize=True is not implemented by the HIP engine")
+            if k == "maximize":   # every torch.optim class takes it: the update uses the negated gradient
+                kw["maximize"] = bool(v)
                 continue
             if k not in kw:
                 raise TypeError(f"{name}.__init__() got an unexpected keyword argument '{k}'")
@@ -773,7 +772,7 @@ class NonLinear(CVCalculator):
         for k in ("eps", "momentum", "dampening", "alpha", "lr_decay", "initial_accumulator_value"):
             if k in kw:
                 out[k] = float(kw[k])
-        for k in ("amsgrad", "nesterov", "centered"):
+        for k in ("amsgrad", "nesterov", "centered", "maximize"):
             if k in kw:
                 out[k] = bool(kw[k])
         # further constants, in the order of dcv.h's DCV_OPT_* comments

@@ -358,7 +358,7 @@ class Mlp:
                  weight_decay: float = 0.0, optimizer: str = "Adam", amsgrad: bool = False, momentum: float = 0.0,
                  dampening: float = 0.0, nesterov: bool = False, alpha: float = 0.99, centered: bool = False,
                  lr_decay: float = 0.0, initial_accumulator_value: float = 0.0, opt_params=None, dropout=None, seed: int = 0,
-                 batchnorm=None, bn_eps: float = 1e-5, bn_momentum: float = 0.1, device="cuda"):
+                 batchnorm=None, bn_eps: float = 1e-5, bn_momentum: float = 0.1, maximize: bool = False, device="cuda"):
         import ctypes as C
 
         if not torch.cuda.is_available():
@@ -401,6 +401,7 @@ class Mlp:
         for i, b in enumerate(self.batchnorm):
             desc.batchnorm[i] = 1 if b else 0
         desc.bn_eps, desc.bn_momentum = float(bn_eps), float(bn_momentum)
+        desc.maximize = 1 if maximize else 0
         self.dropout = [float(p or 0.0) for p in (dropout if dropout is not None else [0.0] * L)]
         if len(self.dropout) != L:
             raise DcvError("one dropout probability per Linear layer expected")

@@ -39,7 +39,7 @@ extern "C" {
 #define DCV_ESTATE (-4)  /* call order violated */
 #define DCV_ECALLBACK (-5) /* a host callback of the caller reported failure */
 
-#define DCV_ABI_VERSION 3
+#define DCV_ABI_VERSION 4
 
 int dcv_abi_version(void);
 const char* dcv_last_error(void);
@@ -177,6 +177,9 @@ typedef struct dcv_mlp_desc {
      * ones.  weight / bias of the layer follow its Linear in the flat parameter buffer (dcv_mlp_param_offset which = 2, 3). */
     int32_t batchnorm[DCV_MAX_LAYERS];
     double bn_eps, bn_momentum;         /* torch defaults 1e-5, 0.1 */
+    /* torch.optim's `maximize`: the update uses the negated gradient (every optimiser; dcv_mlp_grads still holds the gradient
+     * of the loss).  ABI version 4. */
+    int32_t maximize;
 } dcv_mlp_desc;
 
 typedef struct dcv_mlp dcv_mlp; /* opaque; owns parameters, optimiser state and workspaces */

@@ -27,7 +27,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dcv.h but not exported by libdcv.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
-    assert lib.dcv_abi_version() == 3
+    assert lib.dcv_abi_version() == 4
 
 
 def test_no_cpu_fallback():

@@ -59,6 +59,10 @@ def rel_err(a, b):
     # 4096 pairs + lag = 4106 shared rows: the row-limited weight-gradient plan (mlp.hip: wgrad_plan) takes 16 contraction
     # chunks of 257 rows -- chunk ends that are no stage multiple (the stage tail goes through registers), 64 x 64 tiles
     ([512, 256, 128, 3, "tanh"], 4200, 10, 4096, False),
+    # the reference's DEFAULT loader at the contract batch (random split + shuffle: bench.py's `shuffled` block): 8192
+    # gathered pairs = 2 x 8192 rows through the int64 index, the grouped weight / input gradient launch of mixed tile
+    # families (pair.hip), 64 split-K slabs for layer 0
+    ([512, 256, 128, 3, "tanh"], 8400, 10, 8192, True),
 ])
 def test_deeptica_step_matches_autograd(features, dims, n, lag, batch, gather, mode):
     """One Deep-TICA step (statistics, loss, every gradient) against a FLOAT64 run of the autograd oracle on the same

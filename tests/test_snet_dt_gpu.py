@@ -95,7 +95,7 @@ def test_fused_training_follows_the_oracle():
 
     dims, acts, lag, batch = [54, 16, 8, 2], ["tanh", "tanh", None], 4, 256
     Xn, ref = _setup(dims, acts, 5000, lag, seed=9)
-    eng = hip.Mlp("deep_tica", dims, acts, max_batch=16384, lag=lag, tica_reg=1e-6, lr=2e-3)
+    eng = hip.Mlp("deep_tica", dims, acts, max_batch=40000, lag=lag, tica_reg=1e-6, lr=2e-3)
     push_params(eng, linears_of(ref.nn))
     opt = torch.optim.Adam(ref.parameters(), lr=2e-3)
     Xd, Xt = torch.from_numpy(Xn).cuda(), torch.from_numpy(Xn)
@@ -114,8 +114,10 @@ def test_fused_training_follows_the_oracle():
     for (w, b), lin in zip(eng.get_linears(), linears_of(ref.nn)[:-1]):
         np.testing.assert_allclose(w, lin.weight.detach().numpy(), atol=3e-6 * max(1.0, float(lin.weight.abs().max())))
         np.testing.assert_allclose(b, lin.bias.detach().numpy(), atol=3e-6)
-    big = ar_features(16500, 54, 3)
-    eng.train_step(torch.from_numpy(normalized(big)[0]).cuda(), row0=0, batch=16384)   # 1024 tiles: the general path
+    big = torch.from_numpy(normalized(ar_features(40100, 54, 3))[0]).cuda()
+    eng.train_step(big, row0=0, batch=16384)    # 256 tiles of 128 rows: still the fused kernels
+    assert eng.last_path() == 2
+    eng.train_step(big, row0=0, batch=40000)    # 625 tiles: the general path
     assert eng.last_path() == 0
     eng.close()
 

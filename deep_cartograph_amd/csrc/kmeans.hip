@@ -164,7 +164,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_kernel(const double* _
 // the LDS float64 atomics of the general kernel serialise on the few hot addresses and held it to 1.2 TB/s), waves
 // combine with a butterfly reduce-scatter, then wave order, then block order.  Streams 8 D + 8 bytes per point.
 template <int D, int KMAX>
-__global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const double* __restrict__ P, int64_t n,
+__global__ __launch_bounds__(kKmThreads, (KMAX * (D + 1) > 48 ? 1 : 2)) void kmeans_step_reg_kernel(const double* __restrict__ P, int64_t n,
                                                                      const double* __restrict__ offset,
                                                                      const double* __restrict__ centers, int k,
                                                                      int32_t* __restrict__ labels, double* __restrict__ mindist,
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const doubl
     const int64_t end = begin + per_block < n ? begin + per_block : n;
     // U points per thread are requested before any of them is used: with one point per thread in flight a wave keeps
     // 2 KB outstanding and the pass is bound by load latency (1.4 TB/s), not by HBM
-    constexpr int U = 4;
+    constexpr int U = 2;   // points per thread and batch; two batches alternate (below): four points in flight, two waves per SIMD
     // one point: label, inertia, changed count, sums (the arithmetic is the same whichever way the point was loaded)
     auto take_point = [&](const double (&xr)[D], int64_t i, int32_t old) {
         double x[D];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const doubl
         double bestv = INFINITY;
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
-            if (j < k) {
+            if (KMAX <= 8 || j < k) {   // KMAX <= 8: the kernel is instantiated for the exact count
                 double dot = 0.0;
 #pragma unroll
                 for (int c = 0; c < D; ++c) dot += x[c] * s_c[j * D + c];
@@ -229,65 +229,88 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const doubl
         // correctly rounded acc + x and fma(0, x, acc) is acc (finite x) -- the sums a select + add gives
 #pragma unroll
         for (int j = 0; j < KMAX; ++j) {
-            if (j < k) {
-                const double mj = best == j ? 1.0 : 0.0;
+            if (KMAX <= 8 || j < k) {
+                // the 0 / 1 multiplier as ONE select of its high word, opaque to the optimiser (which otherwise turns
+                // fma(select(c, 1, 0), x, acc) back into select(c, acc + x, acc): two v_cndmask and an add per value)
+                unsigned mhi = best == j ? 0x3FF00000u : 0u;
+                asm volatile("" : "+v"(mhi));
+                const double mj = __hiloint2double((int)mhi, 0);
 #pragma unroll
                 for (int c = 0; c < D; ++c) acc[j * D + c] = fma(mj, x[c], acc[j * D + c]);
                 acc[KMAX * D + j] += mj;
             }
         }
     };
-    if constexpr (D == 4) {
-        // 64-point chunks, wave w of the block takes chunks w, w + 4, ...; U chunks requested before any is used (pair loads: above)
-        const int64_t nchunk = (end - begin + 63) / 64;
-        for (int64_t c0 = wave; c0 < nchunk; c0 += 4 * U) {
-            PairUnits pu[U];
-            int32_t olds[U];
+    // A batch = U points per thread, requested together.  TWO batches alternate: the loads of the next one are issued before the
+    // current one is computed, so a wave has memory requests in flight while it computes (one batch at a time left the pass at
+    // the SUM of its load latency and its ~150 float64 instructions per point: 3.8 TB/s, round 3).
+    struct Batch {
+        PairUnits pu[U];      // D == 4: contiguous 16-byte units, halves swapped between lane pairs (pair_issue / pair_finish)
+        double xs[U][D];      // other D: the lane's own points
+        int32_t olds[U];
+    };
+    const int64_t nchunk = (end - begin + 63) / 64;                                  // D == 4: 64-point chunks, wave w takes w, w + 4, ...
+    const int64_t step = D == 4 ? 4 * U : (int64_t)kKmThreads * U;                    // batch stride in chunks / points
+    const int64_t first = D == 4 ? wave : begin + t, last = D == 4 ? nchunk : end;   // batch positions of this wave / thread
+    auto issue = [&](Batch& b, int64_t pos) {
+        if constexpr (D == 4) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t cb = begin + (c0 + 4 * u) * 64;
-                pair_issue(P, cb, end, lane, pu[u]);
+                const int64_t cb = begin + (pos + 4 * u) * 64;
+                pair_issue(P, cb, end, lane, b.pu[u]);
                 const int64_t i = pair_point(cb, lane);
-                olds[u] = i < end ? labels[i] : 0;
+                b.olds[u] = i < end ? labels[i] : 0;
             }
+        } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t cb = begin + (c0 + 4 * u) * 64;
-                double xr[D];
-                pair_finish(pu[u], lane, xr);   // every lane of the wave takes part in the swap
-                const int64_t i = pair_point(cb, lane);
-                if (i < end) take_point(xr, i, olds[u]);
-            }
-        }
-    } else {
-        for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)kKmThreads * U) {
-            double xs[U][D];
-            int32_t olds[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * kKmThreads;
+                const int64_t i = pos + (int64_t)u * kKmThreads;
+                b.olds[u] = 0;
                 if (i < end) {
                     const double* p = P + i * D;
                     if constexpr (D % 2 == 0) {
 #pragma unroll
                         for (int c = 0; c < D; c += 2) {
                             const double2 v = *reinterpret_cast<const double2*>(p + c);
-                            xs[u][c] = v.x;
-                            xs[u][c + 1] = v.y;
+                            b.xs[u][c] = v.x;
+                            b.xs[u][c + 1] = v.y;
                         }
                     } else {
 #pragma unroll
-                        for (int c = 0; c < D; ++c) xs[u][c] = p[c];
+                        for (int c = 0; c < D; ++c) b.xs[u][c] = p[c];
                     }
-                    olds[u] = labels[i];
+                    b.olds[u] = labels[i];
                 }
             }
+        }
+    };
+    auto process = [&](Batch& b, int64_t pos) {
+        if constexpr (D == 4) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * kKmThreads;
-                if (i >= end) break;
-                take_point(xs[u], i, olds[u]);
+                const int64_t cb = begin + (pos + 4 * u) * 64;
+                double xr[D];
+                pair_finish(b.pu[u], lane, xr);   // every lane of the wave takes part in the swap
+                const int64_t i = pair_point(cb, lane);
+                if (i < end) take_point(xr, i, b.olds[u]);
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = pos + (int64_t)u * kKmThreads;
+                if (i < end) take_point(b.xs[u], i, b.olds[u]);
+            }
+        }
+    };
+    {
+        Batch ba, bb;
+        int64_t pos = first;
+        if (pos < last) issue(ba, pos);
+        for (; pos < last; pos += 2 * step) {
+            if (pos + step < last) issue(bb, pos + step);
+            process(ba, pos);
+            if (pos + 2 * step < last) issue(ba, pos + 2 * step);
+            if (pos + step < last) process(bb, pos + step);
         }
     }
     {
@@ -308,26 +331,30 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_reg_kernel(const doubl
     }
 }
 typedef void (*km_reg_fn_t)(const double*, int64_t, const double*, const double*, int, int32_t*, double*, double*);
+template <int KM>
+static km_reg_fn_t km_reg_fn_d(int d) {
+    switch (d) {
+        case 1: return kmeans_step_reg_kernel<1, KM>;
+        case 2: return kmeans_step_reg_kernel<2, KM>;
+        case 3: return kmeans_step_reg_kernel<3, KM>;
+        case 4: return kmeans_step_reg_kernel<4, KM>;
+        default: return nullptr;
+    }
+}
+// k <= 8: an instantiation for the exact cluster count (the `j < k` tests of a padded count were 158 scalar branches in the
+// point loop of the D = 4, KMAX = 8 kernel: every unrolled centroid its own basic block); 9 .. 16 clusters share KMAX = 16
 static km_reg_fn_t km_reg_fn(int d, int k) {
-    if (k <= 8) {
-        switch (d) {
-            case 1: return kmeans_step_reg_kernel<1, 8>;
-            case 2: return kmeans_step_reg_kernel<2, 8>;
-            case 3: return kmeans_step_reg_kernel<3, 8>;
-            case 4: return kmeans_step_reg_kernel<4, 8>;
-            default: return nullptr;
-        }
+    switch (k) {
+        case 1: return km_reg_fn_d<1>(d);
+        case 2: return km_reg_fn_d<2>(d);
+        case 3: return km_reg_fn_d<3>(d);
+        case 4: return km_reg_fn_d<4>(d);
+        case 5: return km_reg_fn_d<5>(d);
+        case 6: return km_reg_fn_d<6>(d);
+        case 7: return km_reg_fn_d<7>(d);
+        case 8: return km_reg_fn_d<8>(d);
+        default: return k <= 16 ? km_reg_fn_d<16>(d) : nullptr;
     }
-    if (k <= 16) {
-        switch (d) {
-            case 1: return kmeans_step_reg_kernel<1, 16>;
-            case 2: return kmeans_step_reg_kernel<2, 16>;
-            case 3: return kmeans_step_reg_kernel<3, 16>;
-            case 4: return kmeans_step_reg_kernel<4, 16>;
-            default: return nullptr;
-        }
-    }
-    return nullptr;
 }
 
 // acc[i] = sum over the blocks of part[b][i]: one workgroup per output, its threads take b = t, t + 256, ... (all loads
@@ -618,45 +645,64 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
             }
         }
     };
-    if constexpr (D == 4) {   // contiguous 16-byte units + pair swap (pair_issue / pair_finish above)
-        const int64_t nchunk = (end - begin + 63) / 64;
-        for (int64_t c0 = wave; c0 < nchunk; c0 += 4 * U) {
-            PairUnits pu[U];
+    // two alternating batches of U points per thread: the next one's loads are in flight while this one is compared (see
+    // kmeans_step_reg_kernel); D == 4 reads contiguous 16-byte units and swaps halves between lane pairs
+    struct Batch {
+        PairUnits pu[U];
+        double xs[U][D];
+    };
+    const int64_t nchunk = (end - begin + 63) / 64;
+    const int64_t step = D == 4 ? 4 * U : (int64_t)kKmThreads * U;
+    const int64_t first = D == 4 ? wave : begin + t, last = D == 4 ? nchunk : end;
+    auto issue = [&](Batch& b, int64_t pos) {
+        if constexpr (D == 4) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) pair_issue(P, begin + (c0 + 4 * u) * 64, end, lane, pu[u]);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                double xr[D];
-                pair_finish(pu[u], lane, xr);
-                const int64_t i = pair_point(begin + (c0 + 4 * u) * 64, lane);
-                if (i < end) take_point(xr, i);
-            }
-        }
-    } else {
-        for (int64_t i0 = begin + t; i0 < end; i0 += (int64_t)U * kKmThreads) {
-            double x[U][D];
+            for (int u = 0; u < U; ++u) pair_issue(P, begin + (pos + 4 * u) * 64, end, lane, b.pu[u]);
+        } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * kKmThreads;
-                const double* p = P + (i < end ? i : i0) * D;
+                const int64_t i = pos + (int64_t)u * kKmThreads;
+                const double* p = P + (i < end ? i : pos) * D;
                 if constexpr (D % 2 == 0) {
 #pragma unroll
                     for (int q = 0; q < D; q += 2) {
                         const double2 v = *reinterpret_cast<const double2*>(p + q);
-                        x[u][q] = v.x;
-                        x[u][q + 1] = v.y;
+                        b.xs[u][q] = v.x;
+                        b.xs[u][q + 1] = v.y;
                     }
                 } else {
 #pragma unroll
-                    for (int q = 0; q < D; ++q) x[u][q] = p[q];
+                    for (int q = 0; q < D; ++q) b.xs[u][q] = p[q];
                 }
             }
+        }
+    };
+    auto process = [&](Batch& b, int64_t pos) {
+        if constexpr (D == 4) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int64_t i = i0 + (int64_t)u * kKmThreads;
-                if (i >= end) break;
-                take_point(x[u], i);
+                double xr[D];
+                pair_finish(b.pu[u], lane, xr);
+                const int64_t i = pair_point(begin + (pos + 4 * u) * 64, lane);
+                if (i < end) take_point(xr, i);
             }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int64_t i = pos + (int64_t)u * kKmThreads;
+                if (i < end) take_point(b.xs[u], i);
+            }
+        }
+    };
+    {
+        Batch ba, bb;
+        int64_t pos = first;
+        if (pos < last) issue(ba, pos);
+        for (; pos < last; pos += 2 * step) {
+            if (pos + step < last) issue(bb, pos + step);
+            process(ba, pos);
+            if (pos + 2 * step < last) issue(ba, pos + 2 * step);
+            if (pos + step < last) process(bb, pos + step);
         }
     }
 #pragma unroll

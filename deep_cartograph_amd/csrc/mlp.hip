@@ -2466,9 +2466,66 @@ void dp_upper_cb(void* p) {
 }
 }  // namespace
 
+// Data-parallel autoencoder step through the fused small-network launch (snet.hip): the loss gradient of a row needs nothing
+// from the other ranks (the scale 2 / (global batch * F) is known up front), so the whole local forward + backward is the
+// one launch of the single-GPU step; then the squared-error sum is all-reduced and logged, the gradient partials are
+// reduced, the gradient buffer all-reduced, the update applied.  1 = not applicable.
+static int dp_ae_fused(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int64_t global_batch,
+                       int32_t train, dcv_allreduce_fn fn, void* user, void* stream) {
+    if (m->desc.model != DCV_MODEL_AE || m->any_drop || m->any_bn || (m->snet_tried && m->snet == nullptr)) return 1;
+    if (!(Xn_d && batch >= 1 && batch <= m->desc.max_batch && ld >= m->desc.dims[0] && m->log && m->log_cap > 0 && global_batch >= batch)) return 1;
+    hipStream_t s = as_stream(stream);
+    g_launch_ev = LaunchEvents{};
+    ReduceArgsView v;
+    prof_mark(m, 0, 0, 0, s);
+    prof_mark(m, 0, 1, 0, s);
+    int rc = snet_ae_step(m, Xn_d, ld, RowMap{idx_d, row0, 0, 0}, batch, global_batch, train, &v, s, false);
+    if (rc) return rc;
+    prof_mark(m, 0, 0, 1, s);
+    prof_mark(m, 0, 1, 1, s);
+    m->fwd_train = train != 0;
+    if (m->fwd_train) m->cur_step = m->drop_step++;
+    m->head_done = false;
+    m->last_batch = batch;
+    m->last_path = 1;
+    if (fn(user, m->stats, m->stats_len, DCV_DTYPE_F64, DCV_DP_STATS) != 0) {
+        set_error("dcv_mlp_dp_step: the all-reduce callback failed (statistics)");
+        return DCV_ECALLBACK;
+    }
+    hipLaunchKernelGGL(ae_log_kernel, dim3(1), dim3(64), 0, s, m->stats, (double)global_batch, m->desc.dims[0], m->log, m->log_count, m->log_cap,
+                       m->log_width);
+    DCV_CHECK_LAUNCH();
+    if (!train) return DCV_OK;
+    ReduceArgs ra;
+    ra.L = m->L;
+    for (int l = 0; l < m->L; ++l) {
+        const LayerPlan& p = m->layers[l];
+        ReduceDesc& rd = ra.l[l];
+        rd.slab = v.slab[l];
+        rd.bpart = v.bpart[l];
+        rd.w_off = p.w_off;
+        rd.b_off = p.b_off;
+        rd.w_count = (int64_t)p.out * p.in;
+        rd.out = p.out;
+        rd.splits = v.splits[l];
+        rd.bblocks = v.bblocks[l];
+    }
+    rc = launch_reduce(m, ra, 0, m->L, false, OptArgs{}, s);
+    if (rc) return rc;
+    if (fn(user, m->grads, m->n_params, DCV_DTYPE_F32, DCV_DP_GRADS) != 0) {
+        set_error("dcv_mlp_dp_step: the all-reduce callback failed (gradients)");
+        return DCV_ECALLBACK;
+    }
+    return apply_impl(m, stream);
+}
+
 extern "C" int dcv_mlp_dp_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch,
                                int64_t global_batch, int32_t train, int32_t overlap, dcv_allreduce_fn fn, void* user, void* stream) {
     DCV_REQUIRE(m && fn, "dcv_mlp_dp_step: null argument");
+    {
+        const int rcf = dp_ae_fused(m, Xn_d, ld, idx_d, row0, batch, global_batch, train, fn, user, stream);
+        if (rcf != 1) return rcf;
+    }
     // Batch normalisation normalises with the rows of ONE forward call: in a frame-sharded step that would be each rank's
     // local rows, the running statistics would drift apart between the ranks, and N ranks would no longer equal one process
     // on the union batch (which every other part of this step guarantees).  Refused rather than silently different.

@@ -104,8 +104,9 @@ struct ReduceArgsView {
     int bblocks[DCV_MAX_LAYERS];
 };
 // snet.hip: the whole autoencoder step in one launch when the network fits in LDS; 1 = not applicable
-int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int32_t batch, int train, ReduceArgsView* ra,
-                 hipStream_t s);
+// R rows of this rank, `batch` = the GLOBAL batch (loss scale 2 / (batch * F)); write_log = false: the caller logs (after an all-reduce)
+int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
+                 hipStream_t s, bool write_log = true);
 void snet_free(dcv_mlp* m);
 // snet_dt.hip: Deep-TICA forward (+ statistics, + loss head) and backward of a network that fits in LDS; 1 = not applicable
 int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,

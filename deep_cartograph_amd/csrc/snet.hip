@@ -305,12 +305,14 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
         if (t == 0) {
             a.stats[0] = tot;
-            const int slot = *a.log_count;
-            if (slot < a.log_cap) {
-                a.log[(int64_t)slot * a.log_width + 0] = tot / (a.Bg * (double)a.l[0].in);
-                a.log[(int64_t)slot * a.log_width + 1] = a.Bg;
+            if (a.log != nullptr) {   // (a data-parallel step logs after the all-reduce of the sum: ae_log_kernel)
+                const int slot = *a.log_count;
+                if (slot < a.log_cap) {
+                    a.log[(int64_t)slot * a.log_width + 0] = tot / (a.Bg * (double)a.l[0].in);
+                    a.log[(int64_t)slot * a.log_width + 1] = a.Bg;
+                }
+                *a.log_count = slot + 1;
             }
-            *a.log_count = slot + 1;
         }
     }
 }
@@ -397,8 +399,8 @@ void snet_free(dcv_mlp* m) {
 // One fused step of the autoencoder over `R` rows (train != 0: gradient partials are left for the reduction, whose
 // descriptors are filled into `ra`).  Returns 1 when the fused form does not apply (the caller takes the layer-by-layer
 // path), DCV_OK when the launch was enqueued.
-int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int32_t batch, int train, ReduceArgsView* ra,
-                 hipStream_t s) {
+int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
+                 hipStream_t s, bool write_log) {
     static const int64_t kMaxPartBytes = 96ll << 20;
     if (m->snet == nullptr) {
         if (m->snet_tried || !snet_build(m)) {
@@ -447,7 +449,7 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     a.ticket = m->ticket;
     a.stats = m->stats;
     a.Bg = (double)batch;
-    a.log = m->log;
+    a.log = write_log ? m->log : nullptr;
     a.log_count = m->log_count;
     a.log_cap = m->log_cap;
     a.log_width = m->log_width;

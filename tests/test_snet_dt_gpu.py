@@ -135,3 +135,67 @@ def test_layer_output_hook_says_when_the_activations_never_left_lds():
     with pytest.raises(DcvError, match="fused small-network"):
         eng.layer_output(0, 128)
     eng.close()
+
+
+class _TwoRanksInOneProcess:
+    """The slice of torch.distributed a data-parallel step touches, for TWO engines stepped one after the other in this
+    process: rank A's call records its buffers, rank B's call adds them up and writes the sums into both -- possible
+    because the collectives of dcv_mlp_dp_step run in a host callback between the library's launches.  (Real two-process
+    runs: tests/test_mlp_gpu.py::test_data_parallel_two_ranks_match_single_process.)"""
+
+    class ReduceOp:
+        SUM = "sum"
+
+
+@pytest.mark.parametrize("model", ["deep_tica", "ae"])
+def test_fused_data_parallel_step_equals_the_single_process_step(model):
+    """dcv_mlp_dp_step on the fused small-network kernels.  With ONE rank (global batch = local batch, all-reduces that
+    change nothing) the data-parallel code path -- fused forward with the head left to the backward launch (Deep-TICA) or the
+    fused step with the loss record written after the statistics exchange (autoencoder), reduction WITHOUT the fused
+    optimiser, separate update -- must land on the weights of dcv_mlp_train_step: same partial sums, same update arithmetic."""
+    from deep_cartograph_amd import hip
+
+    class _OneRank(_TwoRanksInOneProcess):
+        calls = []
+
+        @staticmethod
+        def all_reduce(t, op=None, group=None, async_op=False):
+            _OneRank.calls.append(int(t.numel()))
+            return None
+
+    lag, batch = 3, 512
+    if model == "deep_tica":
+        dims, acts, kw = [54, 16, 8, 2], ["tanh", "tanh", None], dict(lag=lag)
+    else:
+        dims, acts, kw = [54, 16, 2, 16, 54], ["tanh", None, "tanh", None], dict(latent_layer=2)
+    X = ar_features(3000, 54, 41)
+    Xn, m, r = normalized(X)
+    Xd = torch.from_numpy(Xn).cuda()
+    torch.manual_seed(13)
+    lins = [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1)]
+    engs = []
+    for _ in range(2):
+        e = hip.Mlp(model, dims, acts, max_batch=batch, lr=2e-3, **kw)
+        push_params(e, lins)
+        if model == "ae":
+            e.set_feature_range(r)
+        e.reset_log(16)
+        engs.append(e)
+    g = torch.Generator().manual_seed(3)
+    for step in range(5):
+        idx = torch.randperm(Xn.shape[0] - lag, generator=g)[:batch].contiguous().cuda()
+        engs[0].train_step(Xd, idx=idx)
+        engs[1].data_parallel_step(Xd, _OneRank, batch, idx=idx, train=True)
+        assert engs[0].last_path() == (2 if model == "deep_tica" else 1) and engs[1].last_path() == engs[0].last_path()
+    engs[1].data_parallel_step(Xd, _OneRank, batch, idx=idx, train=False)   # evaluation step of the same batch
+    engs[0].eval_step(Xd, idx=idx)
+    ra, rb = engs[0].read_log(), engs[1].read_log()
+    assert len(ra) == 6 and len(rb) == 6
+    np.testing.assert_allclose(rb[:, 0], ra[:, 0], rtol=1e-12, atol=1e-12)   # same sums, same head arithmetic
+    assert np.all(rb[:, 1] == batch)
+    for (wa, ba), (wb, bb) in zip(engs[0].get_linears(), engs[1].get_linears()):
+        np.testing.assert_array_equal(wb, wa)
+        np.testing.assert_array_equal(bb, ba)
+    assert len(_OneRank.calls) == 5 * 2 + 1     # statistics + gradients per training step, statistics for the evaluation step
+    for e in engs:
+        e.close()

@@ -347,7 +347,7 @@ def test_batchnorm_calculator_and_export(features, tmp_path):
     ("ASGD", dict(lr=0.02, lambd=1e-3, alpha=0.75)),
     ("Rprop", dict(lr=1e-3, etas=(0.5, 1.2), step_sizes=(1e-6, 1e-2))),
     ("Adam", dict(lr=1e-3, maximize=True)),             # torch.optim's maximize: the negated gradient drives the update
-    ("SGD", dict(lr=0.01, momentum=0.5, weight_decay=1e-3, maximize=True)),
+    ("SGD", dict(lr=1e-4, weight_decay=1e-3, maximize=True)),      # (a gentle ascent: with momentum the maximised loss diverges within the 12 steps)
 ])
 def test_optimizers_follow_torch(name, kwargs):
     """optimizer.name / kwargs of the YAML (cv_calculator.py:1377-1380 -> getattr(torch.optim, name)): 12 AE steps on the

@@ -70,7 +70,12 @@ struct ReduceDesc {
     int64_t w_count;     // out*in
     int out;
     int splits, bblocks;
+    int64_t w_stride, b_stride;   // floats between consecutive partials (0: dense = w_count / out).  The fused small-network
+                                  // kernels pad them to multiples of 4 so that 16-byte loads work for any layer size (15-wide
+                                  // layers: 810 = 54 * 15 weights per partial took the scalar walk, 15 us per reduction)
 };
+static inline int64_t rd_wstride(const ReduceDesc& d) { return d.w_stride > 0 ? d.w_stride : d.w_count; }
+static inline int64_t rd_bstride(const ReduceDesc& d) { return d.b_stride > 0 ? d.b_stride : (int64_t)d.out; }
 struct ReduceArgs {
     ReduceDesc l[2 * DCV_MAX_LAYERS];   // [0, L): the Linear layers; [L, 2 L): weight / bias of the batch normalisation behind layer l - L (empty without one)
     int L;
@@ -257,11 +262,11 @@ __global__ __launch_bounds__(64 * kRedWaves) void reduce_grads_kernel(ReduceArgs
         if (i < d.w_count) {
             const float* p = d.slab + i;
 #pragma unroll 8
-            for (int q = wave; q < d.splits; q += kRedWaves) s += (double)p[(int64_t)q * d.w_count];
+            for (int q = wave; q < d.splits; q += kRedWaves) s += (double)p[(int64_t)q * (d.w_stride > 0 ? d.w_stride : d.w_count)];
         } else if (i < total) {
             const float* p = d.bpart + (i - d.w_count);
 #pragma unroll 8
-            for (int q = wave; q < d.bblocks; q += kRedWaves) s += (double)p[(int64_t)q * d.out];
+            for (int q = wave; q < d.bblocks; q += kRedWaves) s += (double)p[(int64_t)q * (d.b_stride > 0 ? d.b_stride : (int64_t)d.out)];
         }
         s_red[wave][lane] = s;
         __syncthreads();
@@ -296,11 +301,11 @@ __global__ __launch_bounds__(256) void reduce_grads_small_kernel(ReduceArgs a, f
         if (i < d.w_count) {
             const float* p = d.slab + i;
 #pragma unroll 8
-            for (int q = wave; q < d.splits; q += 4) s += (double)p[(int64_t)q * d.w_count];
+            for (int q = wave; q < d.splits; q += 4) s += (double)p[(int64_t)q * (d.w_stride > 0 ? d.w_stride : d.w_count)];
         } else if (i < total) {
             const float* p = d.bpart + (i - d.w_count);
 #pragma unroll 8
-            for (int q = wave; q < d.bblocks; q += 4) s += (double)p[(int64_t)q * d.out];
+            for (int q = wave; q < d.bblocks; q += 4) s += (double)p[(int64_t)q * (d.b_stride > 0 ? d.b_stride : (int64_t)d.out)];
         }
         s_red[wave][lane] = s;
         __syncthreads();
@@ -325,8 +330,9 @@ __global__ __launch_bounds__(256) void reduce_grads_small_kernel(ReduceArgs a, f
 // groups combined in order, float64: deterministic -- and its parameter load was issued before the partials were
 // waited for.
 struct QuadItem {
-    const float* src;   // [parts][count]
+    const float* src;   // [parts][stride], count <= stride values used
     int64_t dst;        // offset of element 0 in grads / params
+    int64_t stride;     // floats between partials
     int count, parts;
     int blk0;           // first block of this item in the grid
     int groups;         // G
@@ -349,11 +355,12 @@ __device__ __forceinline__ void reduce_quad_block(const QuadItem& d, int blk, fl
     if (fuse && fin) pi = params[d.dst + mine];
     const int e0 = base + 4 * sub;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    if (e0 + 4 <= d.count && (d.count & 3) == 0 && (reinterpret_cast<uintptr_t>(d.src) & 15) == 0) {
+    if (e0 < d.count && (d.stride & 3) == 0 && e0 + 4 <= d.stride && (reinterpret_cast<uintptr_t>(d.src) & 15) == 0) {
+        // (the last quad of a partial may reach into its padding: those elements are summed and never finished)
         const float* p = d.src + e0;
 #pragma unroll 8
         for (int q = g; q < d.parts; q += G) {
-            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)q * d.count);
+            const float4 v = *reinterpret_cast<const float4*>(p + (int64_t)q * d.stride);
             acc[0] += (double)v.x;
             acc[1] += (double)v.y;
             acc[2] += (double)v.z;
@@ -366,7 +373,7 @@ __device__ __forceinline__ void reduce_quad_block(const QuadItem& d, int blk, fl
         for (int q = g; q < d.parts; q += G) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (j < nv) acc[j] += (double)p[(int64_t)q * d.count + j];
+                if (j < nv) acc[j] += (double)p[(int64_t)q * d.stride + j];
         }
     }
 #pragma unroll
@@ -1907,17 +1914,17 @@ static int launch_reduce(dcv_mlp* m, const ReduceArgs& ra_all, int l0, int l1, b
         QuadArgs qa;
         qa.n = 0;
         int64_t blocks = 0;
-        auto item = [&](const float* src, int64_t dst, int64_t count, int parts) {
+        auto item = [&](const float* src, int64_t dst, int64_t count, int parts, int64_t stride) {
             if (count <= 0) return;
             if (!src || parts < 0) parts = 0;   // no partials: a zero gradient, as the other two kernels give
             QuadItem& q = qa.it[qa.n++];
-            q = QuadItem{src, dst, (int)count, parts, (int)blocks, quad_groups(parts)};
+            q = QuadItem{src, dst, stride, (int)count, parts, (int)blocks, quad_groups(parts)};
             blocks += cdiv(count, 1024 / q.groups);
         };
         for (int l = 0; l < ra.L; ++l) {
             DCV_REQUIRE(ra.l[l].w_count < (1ll << 31), "reduce: layer too large");
-            item(ra.l[l].slab, ra.l[l].w_off, ra.l[l].w_count, ra.l[l].splits);
-            item(ra.l[l].bpart, ra.l[l].b_off, ra.l[l].out, ra.l[l].bblocks);
+            item(ra.l[l].slab, ra.l[l].w_off, ra.l[l].w_count, ra.l[l].splits, rd_wstride(ra.l[l]));
+            item(ra.l[l].bpart, ra.l[l].b_off, ra.l[l].out, ra.l[l].bblocks, rd_bstride(ra.l[l]));
         }
         if (blocks <= 0) return DCV_OK;
         DCV_REQUIRE(blocks < (1ll << 31), "reduce: grid out of range");
@@ -2013,6 +2020,8 @@ static int backward_impl(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_
                 rd.out = p.out;
                 rd.splits = v.splits[l];
                 rd.bblocks = v.bblocks[l];
+                rd.w_stride = v.wstride[l];
+                rd.b_stride = v.bstride[l];
             }
             bool upper = false;
             if (L > 1 && m->upper_cb && !fuse_opt) {   // data-parallel overlap hook: the upper layers' gradients first
@@ -2400,6 +2409,8 @@ static int snet_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* i
         rd.out = p.out;
         rd.splits = v.splits[l];
         rd.bblocks = v.bblocks[l];
+        rd.w_stride = v.wstride[l];
+        rd.b_stride = v.bstride[l];
     }
     const int rcf = first_step_state(m, s);
     if (rcf) return rcf;
@@ -2509,6 +2520,8 @@ static int dp_ae_fused(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t*
         rd.out = p.out;
         rd.splits = v.splits[l];
         rd.bblocks = v.bblocks[l];
+        rd.w_stride = v.wstride[l];
+        rd.b_stride = v.bstride[l];
     }
     rc = launch_reduce(m, ra, 0, m->L, false, OptArgs{}, s);
     if (rc) return rc;

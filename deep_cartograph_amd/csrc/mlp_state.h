@@ -102,6 +102,7 @@ struct ReduceArgsView {
     const float* bpart[DCV_MAX_LAYERS];
     int splits[DCV_MAX_LAYERS];
     int bblocks[DCV_MAX_LAYERS];
+    int64_t wstride[DCV_MAX_LAYERS], bstride[DCV_MAX_LAYERS];   // floats between consecutive partials (multiples of 4)
 };
 // snet.hip: the whole autoencoder step in one launch when the network fits in LDS; 1 = not applicable
 // R rows of this rank, `batch` = the GLOBAL batch (loss scale 2 / (batch * F)); write_log = false: the caller logs (after an all-reduce)

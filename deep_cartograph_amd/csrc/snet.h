@@ -19,7 +19,8 @@ struct SnetLayer {
     int u4_begin, c4_shift;     // staging: first 16-byte unit of this layer's weight image in the flat unit space; log2(pin / 4)
     int64_t w_off, b_off;       // flat parameter buffer
     int lw, lb, pws;            // LDS float offsets of the weight image [pout][pws] and the bias [pout]; pws = pin + 4
-    int64_t pw_off, pb_off;     // gradient partials: part + pw_off + wg * out * in ; part + pb_off + wg * out
+    int64_t pw_off, pb_off;     // gradient partials: part + pw_off + wg * pw_stride ; part + pb_off + wg * pb_stride
+    int pw_stride, pb_stride;   // out * in and out rounded up to multiples of 4 floats (16-byte loads in the reduction)
 };
 __device__ __forceinline__ sv4f mfma4(float a, float b, sv4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -176,7 +177,9 @@ inline bool snet_layout(const dcv_mlp* m, SnetLayer* ly, std::vector<int2>& tab,
         y.lw = fl; fl += y.pout * y.pws;
         y.lb = fl; fl += y.pout;
         y.pw_off = y.pb_off = 0;
-        per_wg += (int64_t)p.out * p.in + p.out;
+        y.pw_stride = (p.out * p.in + 3) / 4 * 4;
+        y.pb_stride = (p.out + 3) / 4 * 4;
+        per_wg += (int64_t)((p.out * p.in + 3) / 4 * 4) + (p.out + 3) / 4 * 4;
         if (tab_begin) tab_begin[l] = (int)tab.size();
         const bool vec = (p.in % 4 == 0) && (p.w_off % 4 == 0);
         for (int o = 0; o < y.pout; ++o)

@@ -235,8 +235,8 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
             // weight gradient of the tile: the nk_out x nk_in tiles round-robin over the waves
             {
                 const int nti = y.nk_in, ntot = y.nk_out * nti;
-                float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.out * y.in;
-                const bool vec_ok = (y.in & 3) == 0 && ((y.pw_off + (int64_t)blockIdx.x * y.out * y.in) & 3) == 0;   // a.part is a hipMalloc base
+                float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.pw_stride;
+                const bool vec_ok = (y.in & 3) == 0 && ((y.pw_off + (int64_t)blockIdx.x * y.pw_stride) & 3) == 0;   // a.part is a hipMalloc base
                 int ot = 0, it = wave;
                 while (it >= nti) { it -= nti; ++ot; }
 #pragma unroll 2
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                     for (int r = 0; r < TR / 4; ++r) s += dZ[(part * (TR / 4) + r) * psz + o];
                     s += __shfl_xor(s, 1, 64);
                     s += __shfl_xor(s, 2, 64);
-                    if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.out + o] = s;
+                    if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.pb_stride + o] = s;
                 }
             }
             SNET_STAMP(21 + 2 * l);
@@ -427,13 +427,15 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     int64_t off = 0;
     for (int l = 0; l < m->L; ++l) {
         SnetLayer& y = a.l[l];
-        y.pw_off = off; off += (nwg * (int64_t)y.out * y.in + 3) / 4 * 4;   // 16-byte aligned items (vector stores here, vector loads in the reduction)
-        y.pb_off = off; off += (nwg * (int64_t)y.out + 3) / 4 * 4;
+        y.pw_off = off; off += nwg * (int64_t)y.pw_stride;   // 16-byte aligned items (vector stores here, vector loads in the reduction)
+        y.pb_off = off; off += nwg * (int64_t)y.pb_stride;
         if (ra) {
             ra->slab[l] = pl->part + y.pw_off;
             ra->bpart[l] = pl->part + y.pb_off;
             ra->splits[l] = (int)nwg;
             ra->bblocks[l] = (int)nwg;
+            ra->wstride[l] = y.pw_stride;
+            ra->bstride[l] = y.pb_stride;
         }
     }
     a.params = m->params;

@@ -451,8 +451,8 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
         }
         {
             const int nti = y.nk_in, ntot = y.nk_out * nti;
-            float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.out * y.in;
-            const bool vec_ok = (y.in & 3) == 0 && ((y.pw_off + (int64_t)blockIdx.x * y.out * y.in) & 3) == 0;
+            float* pw = a.part + y.pw_off + (int64_t)blockIdx.x * y.pw_stride;
+            const bool vec_ok = (y.in & 3) == 0 && ((y.pw_off + (int64_t)blockIdx.x * y.pw_stride) & 3) == 0;
             int ot = 0, it = wave;
             while (it >= nti) { it -= nti; ++ot; }
 #pragma unroll 2
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
                 for (int r = 0; r < TR / 4; ++r) s += dZ[(part * (TR / 4) + r) * psz + o];
                 s += __shfl_xor(s, 1, 64);
                 s += __shfl_xor(s, 2, 64);
-                if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.out + o] = s;
+                if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.pb_stride + o] = s;
             }
         }
         if (l == 0) break;
@@ -707,12 +707,14 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head,
     int64_t off = 0;
     for (int l = 0; l < m->L; ++l) {
         SnetLayer& y = a.l[l];
-        y.pw_off = off; off += (nwg * (int64_t)y.out * y.in + 3) / 4 * 4;
-        y.pb_off = off; off += (nwg * (int64_t)y.out + 3) / 4 * 4;
+        y.pw_off = off; off += nwg * (int64_t)y.pw_stride;
+        y.pb_off = off; off += nwg * (int64_t)y.pb_stride;
         ra->slab[l] = pl->part + y.pw_off;
         ra->bpart[l] = pl->part + y.pb_off;
         ra->splits[l] = (int)nwg;
         ra->bblocks[l] = (int)nwg;
+        ra->wstride[l] = y.pw_stride;
+        ra->bstride[l] = y.pb_stride;
     }
     a.params = m->params;
     a.B = batch;

@@ -414,7 +414,8 @@ def test_lazy_optimizer_state_sees_the_schedulers_lr(name, kwargs):
     push_params(eng, lins)
     eng.set_feature_range(r)
     opt = getattr(torch.optim, name)(ref.parameters(), **kwargs)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=20 * kwargs["lr"], total_steps=steps, cycle_momentum=False)
+    # (ASGD with lr up to 0.4 diverges on this problem -- weights of 1e4 after ten steps, where two float32 runs part ways)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=(20 if name == "Rprop" else 2) * kwargs["lr"], total_steps=steps, cycle_momentum=False)
     assert abs(opt.param_groups[0]["lr"] - kwargs["lr"]) > 0.1 * kwargs["lr"]   # the constructor has already moved the lr
     Xd = torch.from_numpy(Xn).cuda()
     Xt = torch.from_numpy(X)

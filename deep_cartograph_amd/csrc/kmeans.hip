@@ -53,10 +53,15 @@ struct PairUnits {
 };
 __device__ __forceinline__ int64_t pair_point(int64_t chunk_base, int lane) { return chunk_base + (lane >> 1) + ((lane & 1) ? 32 : 0); }
 __device__ __forceinline__ void pair_issue(const double* __restrict__ P, int64_t chunk_base, int64_t end, int lane, PairUnits& r) {
-    const int64_t pa = chunk_base + (lane >> 1), pb = pa + 32;
+    // UNCONDITIONAL loads from clamped indices (points past `end` are masked where they are used): a load inside a branch
+    // makes hipcc's wait-count analysis give up -- it put s_waitcnt vmcnt(0) right behind the NEXT batch's loads, so nothing
+    // was ever in flight during the compute (round 4: both passes sat at 3.9 TB/s whatever their arithmetic)
+    int64_t pa = chunk_base + (lane >> 1), pb = pa + 32;
+    pa = pa < end ? pa : end - 1;
+    pb = pb < end ? pb : end - 1;
     const int h = 2 * (lane & 1);
-    r.a = pa < end ? *reinterpret_cast<const double2*>(P + pa * 4 + h) : make_double2(0.0, 0.0);
-    r.b = pb < end ? *reinterpret_cast<const double2*>(P + pb * 4 + h) : make_double2(0.0, 0.0);
+    r.a = *reinterpret_cast<const double2*>(P + pa * 4 + h);
+    r.b = *reinterpret_cast<const double2*>(P + pb * 4 + h);
 }
 __device__ __forceinline__ double dpp_swap_pair(double v) {
     const long long u = __double_as_longlong(v);
@@ -73,6 +78,95 @@ __device__ __forceinline__ void pair_finish(const PairUnits& r, int lane, double
     x[2] = odd ? r.b.x : sax;
     x[3] = odd ? r.b.y : say;
 }
+
+// ---- per-wave LDS-DMA ring for the point stream (D = 2 or 4 coordinates).  What bounded both streaming passes of this file
+// at ~4 TB/s (round 4) was the number of bytes a CU keeps in flight: the points of a batch sit in VGPRs from issue to use, the
+// k-means pass holds ~100 accumulator registers besides, two waves per SIMD x two points per lane = 37 KB per CU against the
+// ~50-70 KB that 6 TB/s x 2 us of loaded latency ask for.  Here every wave owns kRingSlots slots of 64 points in LDS and keeps
+// kRingSlots - 1 chunks requested ahead with global_load_lds (no VGPR between memory and LDS: 16 waves x 3 slots x 2 KB = 96 KB
+// per CU in flight); a lane then reads ITS point from the slot (the pair swap of the register path is not needed).  Only the
+// issuing wave reads its slots: the covering s_waitcnt vmcnt(N) is all the synchronisation there is (MI355X_MICROARCH.md, "Two
+// waves per SIMD", item 7).  vmcnt counts loads, LDS-DMA and stores together in issue order; the loop below issues nothing
+// but its own DMAs and (k-means) ONE label store per chunk, so the number of younger operations is known exactly.
+constexpr int kRingSlots = 4;   // (k-means: 110 VGPRs -> four blocks per CU fit beside 4 x 36 KB of rings: 16 waves x 3 slots x 2.25 KB = 108 KB in flight)
+__device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_wave_addr) {   // 4 bytes per lane: LDS[m0 + 4 * lane]
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dword %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_addr)
+        : "memory");
+}
+__device__ __forceinline__ void vm_wait_dyn(int n) {   // s_waitcnt vmcnt(min(n, 31)): fewer allowed in flight only waits longer
+    n = __builtin_amdgcn_readfirstlane(n);   // wave-uniform by construction: a scalar branch, not an exec-masked tree
+    switch (n) {
+#define DCV_VMW(N) case N: vm_wait<N>(); break;
+        DCV_VMW(0) DCV_VMW(1) DCV_VMW(2) DCV_VMW(3) DCV_VMW(4) DCV_VMW(5) DCV_VMW(6) DCV_VMW(7) DCV_VMW(8) DCV_VMW(9) DCV_VMW(10)
+        DCV_VMW(11) DCV_VMW(12) DCV_VMW(13) DCV_VMW(14) DCV_VMW(15) DCV_VMW(16) DCV_VMW(17) DCV_VMW(18) DCV_VMW(19) DCV_VMW(20)
+        DCV_VMW(21) DCV_VMW(22) DCV_VMW(23) DCV_VMW(24) DCV_VMW(25) DCV_VMW(26) DCV_VMW(27) DCV_VMW(28) DCV_VMW(29) DCV_VMW(30)
+#undef DCV_VMW
+        default: vm_wait<31>(); break;
+    }
+}
+// Streams the points [begin, end) of a block through the calling wave's ring: chunk kk of the wave is the 64 points from
+// begin + (wave + 4 kk) * 64; f(x, i, old) is called for every valid point by its lane (old: the point's previous label when
+// LABELS, else 0).  stores_per_chunk: vector-memory stores f issues per chunk (they count in vmcnt).
+template <int D, bool LABELS, class F>
+__device__ __forceinline__ void ring_stream(const double* __restrict__ P, const int32_t* __restrict__ labels, int64_t begin, int64_t end, char* ring,
+                                            int wave, int lane, int stores_per_chunk, F&& f) {
+    static_assert(D == 2 || D == 4, "ring: 16-byte units");
+    constexpr int UNITS = D / 2, OPS = UNITS + (LABELS ? 1 : 0), SLOT = UNITS * 1024 + (LABELS ? 256 : 0);
+    char* my = ring + wave * kRingSlots * SLOT;
+    const unsigned my_lds = lds_addr_uniform(reinterpret_cast<const float*>(my));
+    const int64_t nchunk = (end - begin + 63) / 64;
+    const int64_t nw = nchunk > wave ? (nchunk - wave + 3) / 4 : 0;
+    const char* Pb = reinterpret_cast<const char*>(P);
+    const int64_t max_off = end * (int64_t)(D * 8) - 16;
+    auto issue = [&](int64_t kk) {
+        const int64_t cb = begin + (wave + 4 * kk) * 64;
+        const unsigned slot = my_lds + (unsigned)(kk % kRingSlots) * SLOT;
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) {
+            int64_t off = cb * (int64_t)(D * 8) + u * 1024 + lane * 16;
+            off = off < max_off ? off : max_off;   // units past the block's range re-read its last unit (never used)
+            glds16(reinterpret_cast<const float*>(Pb + off), slot + u * 1024);
+        }
+        if constexpr (LABELS) {
+            int64_t li = cb + lane;
+            li = li < end ? li : end - 1;
+            glds4(labels + li, slot + UNITS * 1024);
+        }
+    };
+    for (int64_t kk = 0; kk < kRingSlots - 1 && kk < nw; ++kk) issue(kk);
+    for (int64_t kk = 0; kk < nw; ++kk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the slot about to be refilled (chunk kk - 1) has been read
+        if (kk + kRingSlots - 1 < nw) issue(kk + kRingSlots - 1);
+        // operations younger than chunk kk's DMAs: the DMAs of the chunks requested after it and the stores of the chunks
+        // processed since it was requested
+        const int64_t ahead = nw - 1 - kk < kRingSlots - 1 ? nw - 1 - kk : kRingSlots - 1;
+        const int64_t since = kk < kRingSlots - 1 ? kk : kRingSlots - 1;
+        vm_wait_dyn((int)(ahead * OPS + since * stores_per_chunk));
+        const char* slot = my + (kk % kRingSlots) * SLOT;
+        double x[D];
+#pragma unroll
+        for (int c = 0; c < D; c += 2) {
+            const double2 v = *reinterpret_cast<const double2*>(slot + lane * (D * 8) + c * 8);
+            x[c] = v.x;
+            x[c + 1] = v.y;
+        }
+        int32_t old = 0;
+        if constexpr (LABELS) old = *reinterpret_cast<const int32_t*>(slot + UNITS * 1024 + lane * 4);
+        const int64_t i = begin + (wave + 4 * kk) * 64 + lane;
+        if (i < end) f(x, i, old);
+    }
+    vm_wait<0>();
+}
+template <int D, bool LABELS>
+constexpr size_t ring_lds_bytes() { return (size_t)4 * kRingSlots * ((D / 2) * 1024 + (LABELS ? 256 : 0)); }
 
 // acc layout per block: [sums k*d | counts k | inertia | changed]
 __global__ __launch_bounds__(kKmThreads) void kmeans_step_kernel(const double* __restrict__ P, int64_t n, int d,
@@ -163,7 +257,7 @@ __global__ __launch_bounds__(kKmThreads) void kmeans_step_kernel(const double* _
 // every thread keeps the sums and counts of all clusters in registers (a predicated add per cluster and coordinate;
 // the LDS float64 atomics of the general kernel serialise on the few hot addresses and held it to 1.2 TB/s), waves
 // combine with a butterfly reduce-scatter, then wave order, then block order.  Streams 8 D + 8 bytes per point.
-template <int D, int KMAX>
+template <int D, int KMAX, bool RING = false>
 __global__ __launch_bounds__(kKmThreads, (KMAX * (D + 1) > 48 ? 1 : 2)) void kmeans_step_reg_kernel(const double* __restrict__ P, int64_t n,
                                                                      const double* __restrict__ offset,
                                                                      const double* __restrict__ centers, int k,
@@ -259,28 +353,26 @@ __global__ __launch_bounds__(kKmThreads, (KMAX * (D + 1) > 48 ? 1 : 2)) void kme
                 const int64_t cb = begin + (pos + 4 * u) * 64;
                 pair_issue(P, cb, end, lane, b.pu[u]);
                 const int64_t i = pair_point(cb, lane);
-                b.olds[u] = i < end ? labels[i] : 0;
+                b.olds[u] = labels[i < end ? i : end - 1];
             }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = pos + (int64_t)u * kKmThreads;
-                b.olds[u] = 0;
-                if (i < end) {
-                    const double* p = P + i * D;
-                    if constexpr (D % 2 == 0) {
+                const int64_t ic = i < end ? i : end - 1;   // unconditional loads from a clamped index (see pair_issue)
+                const double* p = P + ic * D;
+                if constexpr (D % 2 == 0) {
 #pragma unroll
-                        for (int c = 0; c < D; c += 2) {
-                            const double2 v = *reinterpret_cast<const double2*>(p + c);
-                            b.xs[u][c] = v.x;
-                            b.xs[u][c + 1] = v.y;
-                        }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < D; ++c) b.xs[u][c] = p[c];
+                    for (int c = 0; c < D; c += 2) {
+                        const double2 v = *reinterpret_cast<const double2*>(p + c);
+                        b.xs[u][c] = v.x;
+                        b.xs[u][c + 1] = v.y;
                     }
-                    b.olds[u] = labels[i];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < D; ++c) b.xs[u][c] = p[c];
                 }
+                b.olds[u] = labels[ic];
             }
         }
     };
@@ -302,7 +394,12 @@ __global__ __launch_bounds__(kKmThreads, (KMAX * (D + 1) > 48 ? 1 : 2)) void kme
             }
         }
     };
-    {
+    if constexpr (RING && (D == 2 || D == 4)) {
+        // the point stream through the wave's LDS-DMA ring (ring_stream above): launched when mindist == nullptr, so the only
+        // vector-memory store per chunk is the label store of take_point
+        extern __shared__ __attribute__((aligned(16))) char s_ring[];
+        ring_stream<D, true>(P, labels, begin, end, s_ring, wave, lane, 1, [&](const double (&xr)[D], int64_t i, int32_t old) { take_point(xr, i, old); });
+    } else {
         Batch ba, bb;
         int64_t pos = first;
         if (pos < last) issue(ba, pos);
@@ -332,7 +429,11 @@ __global__ __launch_bounds__(kKmThreads, (KMAX * (D + 1) > 48 ? 1 : 2)) void kme
 }
 typedef void (*km_reg_fn_t)(const double*, int64_t, const double*, const double*, int, int32_t*, double*, double*);
 template <int KM>
-static km_reg_fn_t km_reg_fn_d(int d) {
+static km_reg_fn_t km_reg_fn_d(int d, bool ring) {
+    if (ring && KM <= 8) {   // (9 .. 16 clusters: the register form; its accumulators leave one wave per SIMD anyway)
+        if (d == 2) return kmeans_step_reg_kernel<2, KM, true>;
+        if (d == 4) return kmeans_step_reg_kernel<4, KM, true>;
+    }
     switch (d) {
         case 1: return kmeans_step_reg_kernel<1, KM>;
         case 2: return kmeans_step_reg_kernel<2, KM>;
@@ -343,18 +444,22 @@ static km_reg_fn_t km_reg_fn_d(int d) {
 }
 // k <= 8: an instantiation for the exact cluster count (the `j < k` tests of a padded count were 158 scalar branches in the
 // point loop of the D = 4, KMAX = 8 kernel: every unrolled centroid its own basic block); 9 .. 16 clusters share KMAX = 16
-static km_reg_fn_t km_reg_fn(int d, int k) {
+static km_reg_fn_t km_reg_fn(int d, int k, bool ring) {
     switch (k) {
-        case 1: return km_reg_fn_d<1>(d);
-        case 2: return km_reg_fn_d<2>(d);
-        case 3: return km_reg_fn_d<3>(d);
-        case 4: return km_reg_fn_d<4>(d);
-        case 5: return km_reg_fn_d<5>(d);
-        case 6: return km_reg_fn_d<6>(d);
-        case 7: return km_reg_fn_d<7>(d);
-        case 8: return km_reg_fn_d<8>(d);
-        default: return k <= 16 ? km_reg_fn_d<16>(d) : nullptr;
+        case 1: return km_reg_fn_d<1>(d, ring);
+        case 2: return km_reg_fn_d<2>(d, ring);
+        case 3: return km_reg_fn_d<3>(d, ring);
+        case 4: return km_reg_fn_d<4>(d, ring);
+        case 5: return km_reg_fn_d<5>(d, ring);
+        case 6: return km_reg_fn_d<6>(d, ring);
+        case 7: return km_reg_fn_d<7>(d, ring);
+        case 8: return km_reg_fn_d<8>(d, ring);
+        default: return k <= 16 ? km_reg_fn_d<16>(d, false) : nullptr;
     }
+}
+static bool km_ring_enabled() {
+    static const bool on = [] { const char* e = getenv("DCV_KM_RING"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 // acc[i] = sum over the blocks of part[b][i]: one workgroup per output, its threads take b = t, t + 256, ... (all loads
@@ -589,7 +694,7 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_kernel(const double* 
 // centroids beyond KC take further chunks on grid.y.  Same arithmetic (np_norm), same order per thread (increasing row,
 // strict '<'), same lexicographic (distance, row) combination: bit-identical rows.
 constexpr int kNearKC = 8;
-template <int D>
+template <int D, bool RING = false>
 __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const double* __restrict__ P, int64_t n, const double* __restrict__ centers,
                                                                         int k, double* __restrict__ pdist, int64_t* __restrict__ prow) {
     constexpr int KC = kNearKC, U = 4;
@@ -662,7 +767,7 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int64_t i = pos + (int64_t)u * kKmThreads;
-                const double* p = P + (i < end ? i : pos) * D;
+                const double* p = P + (i < end ? i : end - 1) * D;
                 if constexpr (D % 2 == 0) {
 #pragma unroll
                     for (int q = 0; q < D; q += 2) {
@@ -694,7 +799,10 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
             }
         }
     };
-    {
+    if constexpr (RING && (D == 2 || D == 4)) {   // the point stream through the wave's LDS-DMA ring (ring_stream): no store in the loop
+        extern __shared__ __attribute__((aligned(16))) char s_ring[];
+        ring_stream<D, false>(P, nullptr, begin, end, s_ring, wave, lane, 0, [&](const double (&xr)[D], int64_t i, int32_t) { take_point(xr, i); });
+    } else {
         Batch ba, bb;
         int64_t pos = first;
         if (pos < last) issue(ba, pos);
@@ -839,18 +947,20 @@ extern "C" int dcv_kmeans_step(const double* P_d, int64_t n, int32_t d, const do
     const size_t lds = ((size_t)k * d + k + 4 * W + 2 * kKmThreads) * sizeof(double);
     double* part = static_cast<double*>(ws_d);
     static const bool no_reg = [] { const char* e = getenv("DCV_KMEANS_ATOMIC"); return e && e[0] == '1'; }();   // diagnostic: general kernel
-    if (km_reg_fn_t reg = no_reg ? nullptr : km_reg_fn(d, k)) {
+    const bool ring = km_ring_enabled() && mindist_d == nullptr && (d == 2 || d == 4) && k <= 8;
+    const size_t ring_lds = ring ? (d == 4 ? ring_lds_bytes<4, true>() : ring_lds_bytes<2, true>()) : 0;
+    if (km_reg_fn_t reg = no_reg ? nullptr : km_reg_fn(d, k, ring)) {
         // One round of the chip: the register kernel holds ~150 VGPRs (3 blocks per CU), and 1024 equal blocks on 768
         // slots is two rounds with the second a third full (3.5 TB/s).  Blocks = CUs x resident blocks per CU.
         int nbr = nb;
         int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(reg), kKmThreads, 0) == hipSuccess && per_cu > 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(reg), kKmThreads, ring_lds) == hipSuccess && per_cu > 0) {
             const int64_t one_round = (int64_t)num_cus() * per_cu;
             if (nbr > one_round) nbr = (int)one_round;
         } else {
             (void)hipGetLastError();
         }
-        hipLaunchKernelGGL(reg, dim3(nbr), dim3(kKmThreads), 0, s, P_d, n, offset_d, centers_d, (int)k, labels_d, mindist_d, part);
+        hipLaunchKernelGGL(reg, dim3(nbr), dim3(kKmThreads), ring_lds, s, P_d, n, offset_d, centers_d, (int)k, labels_d, mindist_d, part);
         DCV_CHECK_LAUNCH();
         hipLaunchKernelGGL(kmeans_final_kernel, dim3(W + 2), dim3(256), 0, s, part, nbr, W + 2, acc_d);
         DCV_CHECK_LAUNCH();
@@ -882,11 +992,19 @@ extern "C" int dcv_nearest_rows(const double* P_d, int64_t n, int32_t d, const d
     static const bool multi_off = [] { const char* e = getenv("DCV_NEAREST_PER_CENTROID"); return e && e[0] == '1'; }();
     const dim3 gm(nb, (unsigned)cdiv(k, kNearKC));
     if (d <= 4 && !multi_off) {   // one pass over the points per chunk of kNearKC centroids
+        const bool ring = km_ring_enabled();
+        const size_t rl2 = ring_lds_bytes<2, false>(), rl4 = ring_lds_bytes<4, false>();
         switch (d) {
             case 1: hipLaunchKernelGGL(nearest_rows_multi_kernel<1>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
-            case 2: hipLaunchKernelGGL(nearest_rows_multi_kernel<2>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+            case 2:
+                if (ring) hipLaunchKernelGGL((nearest_rows_multi_kernel<2, true>), gm, dim3(kKmThreads), rl2, s, P_d, n, centers_d, (int)k, pdist, prow);
+                else hipLaunchKernelGGL(nearest_rows_multi_kernel<2>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow);
+                break;
             case 3: hipLaunchKernelGGL(nearest_rows_multi_kernel<3>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
-            default: hipLaunchKernelGGL(nearest_rows_multi_kernel<4>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+            default:
+                if (ring) hipLaunchKernelGGL((nearest_rows_multi_kernel<4, true>), gm, dim3(kKmThreads), rl4, s, P_d, n, centers_d, (int)k, pdist, prow);
+                else hipLaunchKernelGGL(nearest_rows_multi_kernel<4>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow);
+                break;
         }
     } else {
         hipLaunchKernelGGL(nearest_rows_kernel, dim3(nb, k), dim3(kKmThreads), 0, s, P_d, n, d, centers_d, pdist, prow);

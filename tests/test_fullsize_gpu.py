@@ -239,7 +239,13 @@ def test_c5_kmeans_pass_properties():
     acc2, _ = hip.kmeans_step(P, C, lab2)
     acc2 = acc2.cpu().numpy()
     assert acc2[k * d + k + 1] == 0 and torch.equal(lab, lab2)
-    np.testing.assert_array_equal(acc2[:k * d + k + 1], acc[:k * d + k + 1])
+    # the pass that also reports per-point distances keeps its points in registers, the plain pass streams them through the
+    # per-wave LDS-DMA ring (kmeans.hip, round 4): two fixed summation orders -- equal counts, sums to rounding;
+    # the SAME pass repeated is bit-identical
+    np.testing.assert_array_equal(acc2[k * d:k * d + k], acc[k * d:k * d + k])
+    np.testing.assert_allclose(acc2[:k * d + k + 1], acc[:k * d + k + 1], rtol=1e-13)
+    acc2b, _ = hip.kmeans_step(P, C, lab2)
+    np.testing.assert_array_equal(acc2b.cpu().numpy()[:k * d + k + 1], acc2[:k * d + k + 1])
     cut = 7_654_321
     la, lb = torch.full((cut,), -1, dtype=torch.int32, device="cuda"), torch.full((n - cut,), -1, dtype=torch.int32, device="cuda")
     a1, _ = hip.kmeans_step(P[:cut], C, la)

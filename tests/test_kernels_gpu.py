@@ -231,6 +231,42 @@ def test_kmeans_step_and_nearest(golden_cluster):
         np.testing.assert_array_equal(nn, d2.argmin(1))
 
 
+@pytest.mark.parametrize("d,k,n", [(4, 6, 200_003), (2, 3, 70_001), (4, 8, 63), (2, 1, 5_000), (4, 9, 30_000)])
+def test_kmeans_pass_through_the_lds_ring(d, k, n):
+    """The plain Lloyd pass (no per-point distances asked for) streams d = 2 / 4 points through the per-wave LDS-DMA ring
+    (kmeans.hip: ring_stream): labels bit-exact against the sklearn formula in NumPy (first minimum wins), sums / counts /
+    inertia / changed against NumPy, the same answers as the register pass (which reports the distances), ragged tails (n not
+    a multiple of 64, fewer points than one chunk), an offset, k = 9 (the register kernel: more than 8 clusters)."""
+    from deep_cartograph_amd import hip
+
+    rng = np.random.Generator(np.random.PCG64(1000 + 10 * d + k))
+    cent = rng.uniform(-1, 1, (k, d))
+    P = np.round(cent[rng.integers(0, k, n)] + 0.15 * rng.standard_normal((n, d)), 4)
+    C = P[rng.choice(n, k, replace=False)] + 1e-3
+    mean = P.mean(0)
+    Pd = dev(P)
+    lab_ring = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    lab_reg = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    acc_ring, none = hip.kmeans_step(Pd, dev(C - mean), lab_ring, offset=dev(mean))
+    acc_reg, md = hip.kmeans_step(Pd, dev(C - mean), lab_reg, offset=dev(mean), want_mindist=True)
+    assert none is None
+    Xc, Cc = P - mean, C - mean
+    ref_lab = ((Cc * Cc).sum(1)[None, :] - 2.0 * (Xc @ Cc.T)).argmin(1)
+    np.testing.assert_array_equal(lab_ring.cpu().numpy(), ref_lab)
+    np.testing.assert_array_equal(lab_reg.cpu().numpy(), ref_lab)
+    sums = np.zeros((k, d))
+    np.add.at(sums, ref_lab, Xc)
+    for acc in (acc_ring.cpu().numpy(), acc_reg.cpu().numpy()):
+        np.testing.assert_allclose(acc[:k * d].reshape(k, d), sums, rtol=1e-12, atol=1e-9)
+        np.testing.assert_array_equal(acc[k * d:k * d + k], np.bincount(ref_lab, minlength=k))
+        np.testing.assert_allclose(acc[k * d + k], ((Xc - Cc[ref_lab]) ** 2).sum(), rtol=1e-12)
+        assert acc[k * d + k + 1] == n
+    again, _ = hip.kmeans_step(Pd, dev(C - mean), lab_ring, offset=dev(mean))      # idempotent, bit for bit
+    again = again.cpu().numpy()
+    assert again[k * d + k + 1] == 0
+    np.testing.assert_array_equal(again[:k * d + k + 1], acc_ring.cpu().numpy()[:k * d + k + 1])
+
+
 def test_nearest_rows_wide_d():
     """numpy's pairwise summation changes form at d >= 8."""
     from deep_cartograph_amd import hip

@@ -101,6 +101,27 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_wave_addr) 
         : "v"(gsrc), "s"(lds_wave_addr)
         : "memory");
 }
+// 16 bytes per lane, non-temporal: the points are streamed once (MI355X_MICROARCH.md, nt-weights: issue -> landed 18 % sooner
+// for once-read streams).  DCV_KM_NT=0 at build time restores the default policy.
+#ifndef DCV_KM_NT
+#define DCV_KM_NT 1
+#endif
+__device__ __forceinline__ void glds16_stream(const float* gsrc, unsigned lds_wave_addr) {
+#if DCV_KM_NT
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off nt\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_wave_addr)
+        : "memory");
+#else
+    glds16(gsrc, lds_wave_addr);
+#endif
+}
 __device__ __forceinline__ void vm_wait_dyn(int n) {   // s_waitcnt vmcnt(min(n, 31)): fewer allowed in flight only waits longer
     n = __builtin_amdgcn_readfirstlane(n);   // wave-uniform by construction: a scalar branch, not an exec-masked tree
     switch (n) {
@@ -133,7 +154,7 @@ __device__ __forceinline__ void ring_stream(const double* __restrict__ P, const 
         for (int u = 0; u < UNITS; ++u) {
             int64_t off = cb * (int64_t)(D * 8) + u * 1024 + lane * 16;
             off = off < max_off ? off : max_off;   // units past the block's range re-read its last unit (never used)
-            glds16(reinterpret_cast<const float*>(Pb + off), slot + u * 1024);
+            glds16_stream(reinterpret_cast<const float*>(Pb + off), slot + u * 1024);
         }
         if constexpr (LABELS) {
             int64_t li = cb + lane;

@@ -95,7 +95,7 @@ __device__ __forceinline__ void glds4(const void* gsrc, unsigned lds_wave_addr) 
         "s_mov_b32 %0, m0\n\t"
         "s_mov_b32 m0, %2\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dword %1, off\n\t"
+        "global_load_lds_dword %1, off nt\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep)
         : "v"(gsrc), "s"(lds_wave_addr)

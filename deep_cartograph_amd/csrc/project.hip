@@ -88,7 +88,10 @@ __global__ __launch_bounds__(kProjThreads) void project_kernel(ProjArgs a) {
 #pragma unroll
             for (int u = 0; u < kRowsInFlight; ++u) {
                 if constexpr (VEC == 4) {
-                    const float4 q = rok[u] ? *reinterpret_cast<const float4*>(rowp[u] + col) : make_float4(0, 0, 0, 0);
+                    // unconditional (rows past the end re-read row 0 and are never stored) and non-temporal: the matrix is streamed once
+                    typedef float nv4 __attribute__((ext_vector_type(4)));
+                    const nv4 qv = __builtin_nontemporal_load(reinterpret_cast<const nv4*>(rowp[u] + col));
+                    const float4 q = make_float4(qv.x, qv.y, qv.z, qv.w);
                     x[u][0] = q.x; x[u][1] = q.y; x[u][2] = q.z; x[u][3] = q.w;
                 } else {
                     x[u][0] = rok[u] ? rowp[u][col] : 0.f;

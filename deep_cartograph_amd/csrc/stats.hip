@@ -231,19 +231,21 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
     const float4 s = *reinterpret_cast<const float4*>(range + 4 * tx);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
-    for (int64_t r = r0 + ty; r < r1; r += (int64_t)lanes * U) {
-        float4 x[U];
+    // Two alternating batches of U rows per thread: the loads of the next batch are issued before this one is divided and
+    // stored (a batch at a time left every wave with nothing in flight during its 50 division instructions per float4), and
+    // they are UNCONDITIONAL loads from clamped rows -- a load inside a branch makes hipcc put s_waitcnt vmcnt(0) behind
+    // it (round 4, kmeans.hip).  In place (Y == X) is safe: a row is read once, before it is written, by the same thread.
+    auto ld = [&](float4 (&x)[U], int64_t r) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int64_t rr = r + (int64_t)u * lanes;
-            if constexpr (NT) {
-                typedef float nv4 __attribute__((ext_vector_type(4)));
-                const nv4 v = rr < r1 ? __builtin_nontemporal_load(reinterpret_cast<const nv4*>(X + rr * ldx + 4 * tx)) : nv4{0.f, 0.f, 0.f, 0.f};
-                x[u] = make_float4(v.x, v.y, v.z, v.w);
-            } else {
-                x[u] = rr < r1 ? *reinterpret_cast<const float4*>(X + rr * ldx + 4 * tx) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            int64_t rr = r + (int64_t)u * lanes;
+            rr = rr < r1 ? rr : r1 - 1;
+            const float* p = X + rr * ldx + 4 * tx;
+            if constexpr (NT) x[u] = nt_load4(p);
+            else x[u] = *reinterpret_cast<const float4*>(p);
         }
+    };
+    auto st = [&](const float4 (&x)[U], int64_t r) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t rr = r + (int64_t)u * lanes;
@@ -261,6 +263,17 @@ __global__ __launch_bounds__(256) void normalize_rows_kernel(const float* __rest
                 }
             }
         }
+    };
+    if (r0 >= r1) return;
+    const int64_t step = (int64_t)lanes * U;
+    float4 xa[U], xb[U];
+    int64_t r = r0 + ty;
+    ld(xa, r);
+    for (; r < r1; r += 2 * step) {
+        ld(xb, r + step);
+        st(xa, r);
+        ld(xa, r + 2 * step);
+        st(xb, r + step);
     }
 }
 

@@ -715,16 +715,17 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_kernel(const double* 
 // centroids beyond KC take further chunks on grid.y.  Same arithmetic (np_norm), same order per thread (increasing row,
 // strict '<'), same lexicographic (distance, row) combination: bit-identical rows.
 constexpr int kNearKC = 8;
-template <int D, bool RING = false>
+// KX > 0: the kernel is instantiated for exactly KX centroids per chunk (no per-centroid `j < kc` test in the point loop)
+template <int D, bool RING = false, int KX = 0>
 __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const double* __restrict__ P, int64_t n, const double* __restrict__ centers,
                                                                         int k, double* __restrict__ pdist, int64_t* __restrict__ prow) {
-    constexpr int KC = kNearKC, U = 4;
+    constexpr int KC = KX > 0 ? KX : kNearKC, U = 4;
     __shared__ double s_c[KC][D];
     __shared__ double s_d[4][KC];
     __shared__ int64_t s_i[4][KC];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int j0 = blockIdx.y * KC;
-    const int kc = k - j0 < KC ? k - j0 : KC;
+    const int kc = KX > 0 ? KX : (k - j0 < KC ? k - j0 : KC);
     if (t < KC * D) {
         const int j = t / D, q = t - j * D;
         s_c[j][q] = j < kc ? centers[(int64_t)(j0 + j) * D + q] : 0.0;
@@ -745,7 +746,7 @@ __global__ __launch_bounds__(kKmThreads) void nearest_rows_multi_kernel(const do
     auto take_point = [&](const double (&xr)[D], int64_t i) {
 #pragma unroll
         for (int j = 0; j < KC; ++j) {
-            if (j < kc) {
+            if (KX > 0 || j < kc) {
                 // np_norm for D < 8: sequentially added, separately rounded squares (no fma contraction: see np_norm)
                 double res = 0.0;
                 {
@@ -1023,7 +1024,13 @@ extern "C" int dcv_nearest_rows(const double* P_d, int64_t n, int32_t d, const d
                 break;
             case 3: hipLaunchKernelGGL(nearest_rows_multi_kernel<3>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow); break;
             default:
-                if (ring) hipLaunchKernelGGL((nearest_rows_multi_kernel<4, true>), gm, dim3(kKmThreads), rl4, s, P_d, n, centers_d, (int)k, pdist, prow);
+                if (ring && k <= kNearKC) {   // one chunk of exactly k centroids
+                    switch (k) {
+#define DCV_NR4(K) case K: hipLaunchKernelGGL((nearest_rows_multi_kernel<4, true, K>), gm, dim3(kKmThreads), rl4, s, P_d, n, centers_d, (int)k, pdist, prow); break;
+                        DCV_NR4(1) DCV_NR4(2) DCV_NR4(3) DCV_NR4(4) DCV_NR4(5) DCV_NR4(6) DCV_NR4(7) DCV_NR4(8)
+#undef DCV_NR4
+                    }
+                } else if (ring) hipLaunchKernelGGL((nearest_rows_multi_kernel<4, true>), gm, dim3(kKmThreads), rl4, s, P_d, n, centers_d, (int)k, pdist, prow);
                 else hipLaunchKernelGGL(nearest_rows_multi_kernel<4>, gm, dim3(kKmThreads), 0, s, P_d, n, centers_d, (int)k, pdist, prow);
                 break;
         }

@@ -381,3 +381,29 @@ def test_bench_without_a_gpu_says_so_before_it_spawns_ranks():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, cwd=root, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode != 0 and "needs an MI355X" in p.stderr and p.stdout.strip() == ""
+
+
+def test_bench_sampling_plan():
+    """bench.py's roofline sampling: never the first timed step (the one right behind the barrier), the
+    two layer-0 products on DIFFERENT steps, five samples of each at the driver's 20 steps, every 8th step in long runs,
+    --profile-every 1 = both products of every step but the first."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    plan = bench.Fit.sample_plan(20, 0)
+    assert 0 not in plan and len(plan) == 10
+    fwd = [i for i, skip in plan.items() if "fwd" not in skip]
+    wgr = [i for i, skip in plan.items() if "wgrad" not in skip]
+    assert len(fwd) == 5 and len(wgr) == 5 and not set(fwd) & set(wgr)
+    long = bench.Fit.sample_plan(2000, 0)
+    assert 0 not in long and len(long) == 500 and all(i % 8 in (1, 5) for i in long)
+    every = bench.Fit.sample_plan(20, 1)
+    assert sorted(every) == list(range(1, 20)) and all(skip == () for skip in every.values())
+    assert bench.Fit.sample_plan(1, 0) == {0: ()}          # a one-step run has only that step

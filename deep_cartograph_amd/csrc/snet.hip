@@ -29,7 +29,6 @@ struct SnetArgs {
     int lh[DCV_MAX_LAYERS + 1];   // LDS float offset of H_l [TR][ps_l]   (H_0 = the input tile)
     int ps[DCV_MAX_LAYERS + 1];   // row stride of H_l = padded width + 4
     int lred;                     // LDS float offset of the reduction scratch (kSnetThreads doubles)
-    int ls[2];                    // LDS float offsets of two spare gradient buffers [TR][max ps] (decoupled backward), or -1
     const float* params;
     const float* Xn;
     int64_t ld;
@@ -209,18 +208,12 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
         }
     }
     SNET_STAMP(20);
-    // ---- backward chain.  In place (no spare LDS): dZ_l lives in the buffer of H_{l+1}; dZ_{l-1} is written over H_l once
-    //      the weight gradient of layer l (which reads H_l) has been formed by every wave -- two barriers per layer, and the
-    //      input gradient waits in registers behind the weight gradient.  DECOUPLED (round 4, a.ls[0] >= 0): dZ_{l-1} goes
-    //      to one of two spare buffers (ping-pong; they sit in the dead image of W_0 when LDS is otherwise full: the
-    //      backward never reads W_0), every H_l stays intact, so the input gradient of layer l and its weight / bias
-    //      gradients are ONE phase of independent work (the compiler interleaves their LDS reads and MFMA chains) behind
-    //      ONE barrier.
+    // ---- backward chain: dZ_l lives in the buffer of H_{l+1}; dZ_{l-1} is written over H_l once the weight gradient
+    //      of layer l (which reads H_l) has been formed by every wave
     if (a.train) {
-        const bool dec = a.ls[0] >= 0;
         for (int l = L - 1; l >= 0; --l) {
             const SnetLayer& y = a.l[l];
-            const float* dZ = sl + ((dec && l < L - 1) ? a.ls[l & 1] : a.lh[l + 1]);
+            const float* dZ = sl + a.lh[l + 1];
             float* Hin = sl + a.lh[l];
             const int psz = a.ps[l + 1], psh = a.ps[l];
             // input gradient first, kept in registers
@@ -237,24 +230,6 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                 }
                 SNET_NK_SWITCH(y.nk_out, SNET_DGRAD)
 #undef SNET_DGRAD
-                if (dec) {   // dZ_{l-1} = (dZ_l W_l) * act'(H_l) straight into the spare buffer: H_l is only read
-                    float* S = sl + a.ls[(l - 1) & 1];
-                    const int act_prev = a.l[l - 1].act, out_prev = a.l[l - 1].out;
-#pragma unroll
-                    for (int j = 0; j < kSnetMaxTiles; ++j) {
-                        const int it = cg + j * CG;
-                        if (it < y.nk_in) {
-                            const int col = it * 16 + n;
-                            const float* p = Hin + (rg * 16 + 4 * q) * psh + col;
-                            sv4f h;
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) h[v] = p[v * psh];
-                            const sv4f dh = snet_actgrad4(act_prev, h);
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) S[(rg * 16 + 4 * q + v) * psh + col] = col < out_prev ? dg[j][v] * dh[v] : 0.f;
-                        }
-                    }
-                }
             }
             SNET_STAMP(40 + l);
             // weight gradient of the tile: the nk_out x nk_in tiles round-robin over the waves
@@ -299,8 +274,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
             }
             SNET_STAMP(21 + 2 * l);
             if (l == 0) break;
-            __syncthreads();   // every wave is done reading H_l (in place) / dZ_{l-1} is complete and dZ_l is dead (decoupled)
-            if (dec) continue;
+            __syncthreads();   // every wave is done reading H_l
             const int act_prev = a.l[l - 1].act, out_prev = a.l[l - 1].out;
 #pragma unroll
             for (int j = 0; j < kSnetMaxTiles; ++j) {
@@ -392,25 +366,6 @@ static bool snet_build(dcv_mlp* m) {
         f = (f + 3) / 4 * 4;
         a.lred = f;
         f += 2 * kSnetThreads;   // kSnetThreads doubles
-        // spare gradient buffers of the decoupled backward: behind everything when LDS has the room, else inside the image of
-        // W_0 (dead once layer 0's forward is done: the backward has no input gradient to form for layer 0)
-        a.ls[0] = a.ls[1] = -1;
-        {
-            static const bool dec_off = [] { const char* e = getenv("DCV_SNET_INPLACE"); return e && e[0] == '1'; }();
-            int maxps = 0;
-            for (int l = 1; l < m->L; ++l) maxps = a.ps[l] > maxps ? a.ps[l] : maxps;
-            const int need = TR * maxps;
-            if (!dec_off && m->L > 1 && need > 0) {
-                if ((size_t)(f + 2 * need) * sizeof(float) <= lds_max) {
-                    a.ls[0] = f;
-                    a.ls[1] = f + need;
-                    f += 2 * need;
-                } else if (2 * need <= a.l[0].pout * a.l[0].pws) {
-                    a.ls[0] = a.l[0].lw;
-                    a.ls[1] = a.l[0].lw + need;
-                }
-            }
-        }
         if ((size_t)f * sizeof(float) <= lds_max) {
             pl->TR = TR;
             pl->lds_bytes = (size_t)f * sizeof(float);

@@ -36,7 +36,6 @@ struct SnetDtArgs {
     int lh[DCV_MAX_LAYERS + 1];   // LDS float offset of H_l [TR][ps_l]   (H_0 = the input tile)
     int ps[DCV_MAX_LAYERS + 1];
     int act_len;                  // floats of the activation region [lh[0], lh[0] + act_len): the blob of a workgroup
-    int ls[2];                    // backward: two spare gradient buffers [TR][max ps] (decoupled chain, snet.hip), or -1
     const float* params;
     const float* Xn;
     int64_t ld;
@@ -429,13 +428,11 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
         }
         __syncthreads();
     }
-    // ---- backward chain (snet_ae_kernel): in place -- dZ_l lives in the buffer of H_{l+1}, dZ_{l-1} is written over H_l once
-    //      the weight gradient of layer l has been formed by every wave -- or decoupled (a.ls[0] >= 0): dZ_{l-1} goes to one of
-    //      two spare buffers, input gradient and weight / bias gradients of a layer are one phase behind one barrier
-    const bool dec = a.ls[0] >= 0;
+    // ---- backward chain (snet_ae_kernel): dZ_l lives in the buffer of H_{l+1}; dZ_{l-1} is written over H_l once the weight
+    //      gradient of layer l (which reads H_l) has been formed by every wave
     for (int l = L - 1; l >= 0; --l) {
         const SnetLayer& y = a.l[l];
-        const float* dZ = sl + ((dec && l < L - 1) ? a.ls[l & 1] : a.lh[l + 1]);
+        const float* dZ = sl + a.lh[l + 1];
         float* Hin = sl + a.lh[l];
         const int psz = a.ps[l + 1], psh = a.ps[l];
         sv4f dg[kSnetMaxTiles];
@@ -451,24 +448,6 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
             }
             SNET_NK_SWITCH(y.nk_out, SNET_DGRAD)
 #undef SNET_DGRAD
-            if (dec) {   // dZ_{l-1} = (dZ_l W_l) * act'(H_l) straight into the spare buffer: H_l is only read
-                float* S = sl + a.ls[(l - 1) & 1];
-                const int act_prev = a.l[l - 1].act, out_prev = a.l[l - 1].out;
-#pragma unroll
-                for (int j = 0; j < kSnetMaxTiles; ++j) {
-                    const int it = cg + j * CG;
-                    if (it < y.nk_in) {
-                        const int col = it * 16 + n;
-                        const float* p = Hin + (rg * 16 + 4 * q) * psh + col;
-                        sv4f h;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) h[v] = p[v * psh];
-                        const sv4f dh = snet_actgrad4(act_prev, h);
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) S[(rg * 16 + 4 * q + v) * psh + col] = col < out_prev ? dg[j][v] * dh[v] : 0.f;
-                    }
-                }
-            }
         }
         {
             const int nti = y.nk_in, ntot = y.nk_out * nti;
@@ -504,8 +483,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
             }
         }
         if (l == 0) break;
-        __syncthreads();   // every wave is done reading H_l (in place) / dZ_{l-1} is complete and dZ_l is dead (decoupled)
-        if (dec) continue;
+        __syncthreads();   // every wave is done reading H_l
         const int act_prev = a.l[l - 1].act, out_prev = a.l[l - 1].out;
 #pragma unroll
         for (int j = 0; j < kSnetMaxTiles; ++j) {
@@ -551,25 +529,6 @@ static int snet_dt_map(SnetDtArgs& a, int fl, int TR) {
         f += TR * (P + 4);
     }
     a.act_len = f - a.lh[0];
-    // spare gradient buffers of the decoupled backward: behind the activations when LDS has the room, else inside the image of
-    // W_0 (the backward launch does not even stage it)
-    a.ls[0] = a.ls[1] = -1;
-    {
-        static const bool dec_off = [] { const char* e = getenv("DCV_SNET_INPLACE"); return e && e[0] == '1'; }();
-        int maxps = 0;
-        for (int l = 1; l < a.L; ++l) maxps = a.ps[l] > maxps ? a.ps[l] : maxps;
-        const int need = TR * maxps;
-        if (!dec_off && a.L > 1 && need > 0) {
-            if ((size_t)(f + 2 * need) * sizeof(float) <= kSnetDtLdsMax) {
-                a.ls[0] = f;
-                a.ls[1] = f + need;
-                f += 2 * need;
-            } else if (2 * need <= a.l[0].pout * a.l[0].pws) {
-                a.ls[0] = a.l[0].lw;
-                a.ls[1] = a.l[0].lw + need;
-            }
-        }
-    }
     return f < 2048 ? 2048 : f;   // the last arriver sums the statistics partials in the first 4 KB
 }
 // rows per tile for a batch of B pairs: the smallest tile that keeps the launch at <= 256 workgroups (one per CU; the ticketed

@@ -86,14 +86,16 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
     // ---- stage every weight image and bias (zero-padded, row stride pin + 4) through the plan's staging table: one flat
     //      space of 16-byte units over all layers, twelve independent loads in flight per thread and pass -- two dependent
     //      round trips in all (table entry, then data).  Per-layer loops cost one L2 round trip per pass (8-11 us).
-    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
-        int2 e[12];
-        float4 v[12];
+    // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
+    // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
+    int2 e[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = i0 + NT * u;
-            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-        }
+    for (int u = 0; u < 12; ++u) {
+        const int i = t + NT * u;
+        e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+    }
+    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
+        float4 v[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -120,9 +122,17 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                 if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + a.rows.template get<true>(r0 + r) * a.ld + 4 * c);
             }
         }
+        int2 en[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = i0 + 12 * NT + NT * u;
+            en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
 #pragma unroll
         for (int u = 0; u < 12; ++u)
             if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) e[u] = en[u];
     }
     if (x_vec && !x_issued) {   // (a plan without staging units: not reachable, kept for the invariant xv is loaded)
         const int f4 = F0 >> 2;

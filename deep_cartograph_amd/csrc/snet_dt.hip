@@ -118,14 +118,16 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
         for (int u = 0; u < XA; ++u) xv[u] = load_x(u);
     };
     // ---- stage every weight image and bias (snet.hip: one flat table, twelve loads in flight, two dependent round trips)
-    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
-        int2 e[12];
-        float4 v[12];
+    // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
+    // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
+    int2 e[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = i0 + NT * u;
-            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-        }
+    for (int u = 0; u < 12; ++u) {
+        const int i = t + NT * u;
+        e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+    }
+    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
+        float4 v[12];
 #pragma unroll
         for (int u = 0; u < 12; ++u) {
             v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -146,9 +148,17 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
             x_issued = true;
             issue_x();
         }
+        int2 en[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = i0 + 12 * NT + NT * u;
+            en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
 #pragma unroll
         for (int u = 0; u < 12; ++u)
             if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) e[u] = en[u];
     }
     if (x_vec && !x_issued) issue_x();
     asm volatile("" ::"s"(ka_touch));
@@ -324,14 +334,16 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
             }
         }
     };
-    for (int i0 = a.stage_bwd0 + t; i0 < a.stage_n; i0 += 12 * NT) {
-        int2 e[12];
-        float4 v[12];
+    // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
+    // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
+    int2 e[12];
 #pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = i0 + NT * u;
-            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-        }
+    for (int u = 0; u < 12; ++u) {
+        const int i = a.stage_bwd0 + t + NT * u;
+        e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+    }
+    for (int i0 = a.stage_bwd0 + t; i0 < a.stage_n; i0 += 12 * NT) {
+        float4 v[12];
         if (!blob_issued) {
             blob_issued = true;
             issue_blob();
@@ -353,9 +365,17 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
             }
         }
         if (!head_ran) run_head();   // this wave's table, blob and data loads are in flight
+        int2 en[12];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) {
+            const int i = i0 + 12 * NT + NT * u;
+            en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
 #pragma unroll
         for (int u = 0; u < 12; ++u)
             if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+#pragma unroll
+        for (int u = 0; u < 12; ++u) e[u] = en[u];
     }
     if (!blob_issued) issue_blob();
     if (!head_ran) run_head();

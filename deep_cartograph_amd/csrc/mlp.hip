@@ -94,6 +94,10 @@ struct OptArgs {
     float decay;      // AdamW: 1 - lr * weight_decay
     float p0, p1, p2, p3;   // further per-step scalars of Adamax / NAdam / RAdam / Adadelta / ASGD / Rprop (next_opt_args)
     int maximize;           // torch.optim's maximize: the update runs on the negated gradient
+    // LDS image of the fused small-network kernels (snet.h: snet_image_build): every updated parameter is mirrored into the
+    // zero-padded weight image those kernels stage with one contiguous copy, at img[img_idx[i]] (img_idx[i] < 0: not in it)
+    float* img;
+    const int* img_idx;
 };
 // pi = p[i], loaded by the caller (the reduction kernels issue that load before they wait for the partial sums)
 // WT: write-through stores (the launch then ends without dirty lines to write back: reduce_grads_quad_kernel)
@@ -101,6 +105,14 @@ template <bool WT>
 __device__ __forceinline__ void opt_st(float* p, float v) {
     if constexpr (WT) handoff_store(p, v);
     else *p = v;
+}
+template <bool WT>
+__device__ __forceinline__ void opt_stp(const OptArgs& a, float* p, int64_t i, float v) {
+    opt_st<WT>(p + i, v);
+    if (a.img != nullptr) {
+        const int j = a.img_idx[i];
+        if (j >= 0) opt_st<WT>(a.img + j, v);
+    }
 }
 template <bool WT = false>
 __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
@@ -122,7 +134,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float denom = sqrtf(vden) / a.c2 + a.eps;
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, vi);
-            opt_st<WT>(p + i, pi - a.c1 * (mi / denom));                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+            opt_stp<WT>(a, p, i, pi - a.c1 * (mi / denom));                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
             break;
         }
         case DCV_OPT_SGD: {
@@ -132,7 +144,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
                 opt_st<WT>(s1 + i, bi);
                 gi = a.flag ? fmaf(a.b1, bi, gi) : bi;                            // nesterov: grad.add(buf, alpha=momentum)
             }
-            opt_st<WT>(p + i, pi - a.lr * gi);
+            opt_stp<WT>(a, p, i, pi - a.lr * gi);
             break;
         }
         case DCV_OPT_RMSPROP: {
@@ -151,9 +163,9 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             if (a.b1 > 0.f) {                                                      // b1 = momentum
                 const float bi = s1[i] * a.b1 + gi / avg;                          // buf.mul_(momentum).addcdiv_(grad, avg)
                 opt_st<WT>(s1 + i, bi);
-                opt_st<WT>(p + i, pi - a.lr * bi);
+                opt_stp<WT>(a, p, i, pi - a.lr * bi);
             } else {
-                opt_st<WT>(p + i, pi - a.lr * (gi / avg));
+                opt_stp<WT>(a, p, i, pi - a.lr * (gi / avg));
             }
             break;
         }
@@ -164,7 +176,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float ui = fmaxf(s2[i] * a.b2, fabsf(gi) + a.eps);              // maximum(exp_inf * beta2, |grad| + eps)
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, ui);
-            opt_st<WT>(p + i, pi - a.c1 * (mi / ui));                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
+            opt_stp<WT>(a, p, i, pi - a.c1 * (mi / ui));                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
             break;
         }
         case DCV_OPT_NADAM: {    // _single_tensor_nadam: p0 = -lr (1 - mu) / (1 - mu_product), p1 = -lr mu_next / (1 - mu_product_next), c2 = 1 - beta2^t
@@ -179,7 +191,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, vi);
             pi = pi + a.p0 * (gi / denom);
-            opt_st<WT>(p + i, pi + a.p1 * (mi / denom));
+            opt_stp<WT>(a, p, i, pi + a.p1 * (mi / denom));
             break;
         }
         case DCV_OPT_RADAM: {    // _single_tensor_radam: c1 = 1 - beta1^t, c2 = sqrt(1 - beta2^t), p0 = rect (0: rho_t <= 5)
@@ -193,8 +205,8 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, vi);
             const float mhat = mi / a.c1;
-            if (a.p0 > 0.f) opt_st<WT>(p + i, pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0);
-            else opt_st<WT>(p + i, pi - mhat * a.lr);
+            if (a.p0 > 0.f) opt_stp<WT>(a, p, i, pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0);
+            else opt_stp<WT>(a, p, i, pi - mhat * a.lr);
             break;
         }
         case DCV_OPT_ADADELTA: { // _single_tensor_adadelta: s1 = square_avg, s2 = acc_delta, b2 = rho, w2 = 1 - rho
@@ -204,13 +216,13 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float delta = sqrtf(acc + a.eps) / sqrtf(sq + a.eps) * gi;
             opt_st<WT>(s1 + i, sq);
             opt_st<WT>(s2 + i, acc * a.b2 + a.w2 * delta * delta);
-            opt_st<WT>(p + i, pi - a.lr * delta);
+            opt_stp<WT>(a, p, i, pi - a.lr * delta);
             break;
         }
         case DCV_OPT_ASGD: {     // _single_tensor_asgd: p0 = 1 - lambd * eta, p1 = eta (the averaged copy ax is not kept)
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             pi = pi * a.p0;
-            opt_st<WT>(p + i, pi - a.p1 * gi);
+            opt_stp<WT>(a, p, i, pi - a.p1 * gi);
             break;
         }
         case DCV_OPT_RPROP: {    // _single_tensor_rprop: s1 = prev, s2 = step_size; p0 / p1 = eta minus / plus, p2 / p3 = step bounds
@@ -220,7 +232,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             opt_st<WT>(s2 + i, st);
             if (sg < 0.f) gi = 0.f;
             const float sgn = gi > 0.f ? 1.f : (gi < 0.f ? -1.f : 0.f);
-            opt_st<WT>(p + i, pi - sgn * st);
+            opt_stp<WT>(a, p, i, pi - sgn * st);
             opt_st<WT>(s1 + i, gi);
             break;
         }
@@ -228,7 +240,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             const float su = s2[i] + gi * gi;                                      // state_sum.addcmul_(grad, grad, value=1)
             opt_st<WT>(s2 + i, su);
-            opt_st<WT>(p + i, pi - a.c1 * (gi / (sqrtf(su) + a.eps)));                         // param.addcdiv_(grad, std, value=-clr)
+            opt_stp<WT>(a, p, i, pi - a.c1 * (gi / (sqrtf(su) + a.eps)));                         // param.addcdiv_(grad, std, value=-clr)
             break;
         }
     }
@@ -1260,6 +1272,7 @@ static void mlp_free(dcv_mlp* m) {
     if (!m) return;
     snet_free(m);
     snet_dt_free(m);
+    snet_image_free(m);
     auto f = [](void* p) { if (p) (void)hipFree(p); };
     f(m->params); f(m->grads); f(m->adam_m); f(m->adam_v); f(m->opt_aux); f(m->dZ[0]); f(m->dZ[1]); f(m->stats); f(m->gradp);
     f(m->spart); f(m->log); f(m->log_count); f(m->ticket); f(m->feat_range); f(m->ident); f(m->zeros_d); f(m->ones_d); f(m->proj_ws);
@@ -1360,6 +1373,9 @@ extern "C" int dcv_mlp_create(const dcv_mlp_desc* desc, dcv_mlp** out) {
     m->snet_tried = false;
     m->snet_dt = nullptr;
     m->snet_dt_tried = false;
+    m->snet_img = nullptr;
+    m->snet_img_idx = nullptr;
+    m->snet_img_floats = 0;
     m->snet_fwd_valid = false;
     m->last_path = 0;
     m->prof_level = m->prof_cap = 0;
@@ -1517,6 +1533,7 @@ extern "C" int dcv_mlp_set_params(dcv_mlp* m, const float* params_h, void* strea
     DCV_CHECK_HIP(hipMemcpyAsync(m->params, params_h, m->n_params * sizeof(float), hipMemcpyHostToDevice, s));
     int rc = reset_opt_state(m, s);
     if (rc == DCV_OK) rc = reset_bn_state(m, s);
+    if (rc == DCV_OK) rc = snet_image_repack(m, s);   // the fused small-network kernels' weight image follows the parameters
     if (rc) return rc;
     DCV_CHECK_HIP(hipStreamSynchronize(s));
     return DCV_OK;
@@ -2270,6 +2287,8 @@ static OptArgs next_opt_args(dcv_mlp* m) {
     a.eps = (float)d.eps;
     a.wd = (float)d.weight_decay;
     a.maximize = d.maximize ? 1 : 0;
+    a.img = m->snet_img;
+    a.img_idx = m->snet_img_idx;
     switch (d.optimizer) {
         case DCV_OPT_ADAM:
         case DCV_OPT_ADAMW: {

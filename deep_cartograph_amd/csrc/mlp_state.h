@@ -56,6 +56,9 @@ struct dcv_mlp {
     uint32_t drop_rank;        // mixed into the key of the dropout counters (dcv_mlp_set_rank): the ranks of a data-parallel run draw independent masks
     void* snet;                // plan of the fused small-network step (snet.hip) or null
     bool snet_tried;           // the plan was attempted once (null afterwards = not applicable)
+    float* snet_img;           // zero-padded LDS image of every weight / bias of the fused small-network kernels, kept current by the
+    int* snet_img_idx;         //   optimiser (img[img_idx[i]] mirrors params[i]; -1: not part of the image); null until a plan builds it
+    int snet_img_floats;
     void* snet_dt;             // plan of the fused small-network Deep-TICA forward / backward (snet_dt.hip) or null
     bool snet_dt_tried;
     bool snet_fwd_valid;       // the last forward went through snet_dt_forward and left its blob for the backward
@@ -109,6 +112,11 @@ struct ReduceArgsView {
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
                  hipStream_t s, bool write_log = true);
 void snet_free(dcv_mlp* m);
+// the weight image both fused small-network plans stage from (snet.hip); repack: after the parameters were written by anyone
+// but the optimiser (dcv_mlp_set_params)
+bool snet_image_build(dcv_mlp* m);
+int snet_image_repack(dcv_mlp* m, hipStream_t s);
+void snet_image_free(dcv_mlp* m);
 // snet_dt.hip: Deep-TICA forward (+ statistics, + loss head) and backward of a network that fits in LDS; 1 = not applicable
 int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
                     hipStream_t s);

@@ -154,7 +154,9 @@ constexpr int kSnetMaxTiles = 8;   // column tiles of a layer per wave (input gr
 // bias [pout].  tab: per 16-byte unit of the LDS image {source element offset into params or -1, LDS float offset |
 // valid elements << 20 | 16-byte load legal << 24}; tab_begin[l] = first entry of layer l.  Returns false when a width
 // does not qualify.  fl: floats of LDS the images take; per_wg: floats of one workgroup's gradient partials (dense).
-inline bool snet_layout(const dcv_mlp* m, SnetLayer* ly, std::vector<int2>& tab, int* tab_begin, int& fl, int64_t& per_wg) {
+inline bool snet_layout(const dcv_mlp* m, SnetLayer* ly, std::vector<int2>& tab, int* tab_begin, int& fl, int64_t& per_wg,
+                        std::vector<int>* img_idx = nullptr) {
+    if (img_idx) img_idx->assign((size_t)m->n_params, -1);
     fl = 0;
     per_wg = 0;
     int u4 = 0;
@@ -181,6 +183,12 @@ inline bool snet_layout(const dcv_mlp* m, SnetLayer* ly, std::vector<int2>& tab,
         y.pb_stride = (p.out + 3) / 4 * 4;
         per_wg += (int64_t)((p.out * p.in + 3) / 4 * 4) + (p.out + 3) / 4 * 4;
         if (tab_begin) tab_begin[l] = (int)tab.size();
+        if (img_idx) {   // image float offset of every parameter of this layer
+            for (int o = 0; o < p.out; ++o) {
+                for (int i = 0; i < p.in; ++i) (*img_idx)[(size_t)(p.w_off + (int64_t)o * p.in + i)] = y.lw + o * y.pws + i;
+                (*img_idx)[(size_t)(p.b_off + o)] = y.lb + o;
+            }
+        }
         const bool vec = (p.in % 4 == 0) && (p.w_off % 4 == 0);
         for (int o = 0; o < y.pout; ++o)
             for (int c = 0; c < y.pin / 4; ++c) {
@@ -194,6 +202,19 @@ inline bool snet_layout(const dcv_mlp* m, SnetLayer* ly, std::vector<int2>& tab,
         }
     }
     return fl < (1 << 20) && m->n_params < (1ll << 31);
+}
+
+// Stages floats [f0, f1) of the global weight image (same layout as the LDS image; f0, f1 multiples of 256 floats are not
+// required) into LDS with global_load_lds: no table, no VGPR, every copy of the workgroup in flight at once -- ONE round trip
+// where the table-driven staging took two per pass of 12 units.  Completion: the caller's s_waitcnt vmcnt(0) + barrier.
+template <int NT>
+__device__ __forceinline__ void snet_stage_image(const float* __restrict__ img, float* sl, int f0, int f1, int t) {
+    const int u0 = f0 >> 2, u1 = (f1 + 3) >> 2;
+    for (int ub = u0 + (t & ~63); ub < u1; ub += NT) {   // a wave-instruction covers 64 consecutive 16-byte units
+        const int u = ub + (t & 63);
+        const unsigned ldsw = lds_addr_uniform(sl + 4 * ub);
+        if (u < u1) glds16(img + 4 * u, ldsw);
+    }
 }
 
 inline bool snet_disabled() {

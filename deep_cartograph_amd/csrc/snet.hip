@@ -30,6 +30,8 @@ struct SnetArgs {
     int ps[DCV_MAX_LAYERS + 1];   // row stride of H_l = padded width + 4
     int lred;                     // LDS float offset of the reduction scratch (kSnetThreads doubles)
     const float* params;
+    const float* img;             // global weight image in the LDS layout (snet_image_build), or null: table-driven staging
+    int img_floats;
     const float* Xn;
     int64_t ld;
     RowMap rows;
@@ -86,53 +88,59 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
     // ---- stage every weight image and bias (zero-padded, row stride pin + 4) through the plan's staging table: one flat
     //      space of 16-byte units over all layers, twelve independent loads in flight per thread and pass -- two dependent
     //      round trips in all (table entry, then data).  Per-layer loops cost one L2 round trip per pass (8-11 us).
-    // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
-    // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
-    int2 e[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-        const int i = t + NT * u;
-        e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-    }
-    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
-        float4 v[12];
-#pragma unroll
+    if (a.img != nullptr) {
+        // one contiguous LDS-DMA copy of the whole weight image (kept current by the optimiser: OptArgs::img); the input rows
+        // are requested right behind it
+        snet_stage_image<NT>(a.img, sl, 0, a.img_floats, t);
+    } else {
+        // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
+        // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
+        int2 e[12];
+    #pragma unroll
         for (int u = 0; u < 12; ++u) {
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e[u].x >= 0) {
-                const float* src = a.params + e[u].x;
-                const int nv = (e[u].y >> 20) & 7;
-                if ((e[u].y >> 24) & 1) {
-                    v[u] = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v[u].x = src[0];
-                    if (nv > 1) v[u].y = src[1];
-                    if (nv > 2) v[u].z = src[2];
-                    if (nv > 3) v[u].w = src[3];
+            const int i = t + NT * u;
+            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
+        for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
+            float4 v[12];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e[u].x >= 0) {
+                    const float* src = a.params + e[u].x;
+                    const int nv = (e[u].y >> 20) & 7;
+                    if ((e[u].y >> 24) & 1) {
+                        v[u] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v[u].x = src[0];
+                        if (nv > 1) v[u].y = src[1];
+                        if (nv > 2) v[u].z = src[2];
+                        if (nv > 3) v[u].w = src[3];
+                    }
                 }
             }
-        }
-        if (x_vec && !x_issued) {   // behind the first pass's data loads (loads return in order: issued earlier, the cold
-            x_issued = true;        // rows of X would hold up the table entries; here they ride along the data round trip)
-            const int f4 = F0 >> 2;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
-                xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + a.rows.template get<true>(r0 + r) * a.ld + 4 * c);
+            if (x_vec && !x_issued) {   // behind the first pass's data loads (loads return in order: issued earlier, the cold
+                x_issued = true;        // rows of X would hold up the table entries; here they ride along the data round trip)
+                const int f4 = F0 >> 2;
+    #pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
+                    xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + a.rows.template get<true>(r0 + r) * a.ld + 4 * c);
+                }
             }
+            int2 en[12];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int i = i0 + 12 * NT + NT * u;
+                en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+            }
+    #pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) e[u] = en[u];
         }
-        int2 en[12];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = i0 + 12 * NT + NT * u;
-            en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-        }
-#pragma unroll
-        for (int u = 0; u < 12; ++u)
-            if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) e[u] = en[u];
     }
     if (x_vec && !x_issued) {   // (a plan without staging units: not reachable, kept for the invariant xv is loaded)
         const int f4 = F0 >> 2;
@@ -144,6 +152,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
         }
     }
     asm volatile("" ::"s"(ka_touch));   // the touches have landed
+    if (a.img != nullptr) vm_wait<0>();   // the image copies of this wave have landed (the barrier below covers the other waves)
     SNET_STAMP(1);
     if (x_vec) {
 #pragma unroll
@@ -351,6 +360,7 @@ static bool snet_build(dcv_mlp* m) {
     std::vector<int2> tab;
     if (!snet_layout(m, a.l, tab, nullptr, fl, per_wg)) { delete pl; return false; }
     pl->per_wg = per_wg;
+    (void)snet_image_build(m);   // on failure the kernels keep the table-driven staging
     pl->stage_tab = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&pl->stage_tab), tab.size() * sizeof(int2)) != hipSuccess ||
         hipMemcpy(pl->stage_tab, tab.data(), tab.size() * sizeof(int2), hipMemcpyHostToDevice) != hipSuccess) {
@@ -394,6 +404,64 @@ static bool snet_build(dcv_mlp* m) {
     (void)hipFree(pl->stage_tab);
     delete pl;
     return false;
+}
+
+// ---- the global weight image: every weight / bias at its LDS-image offset, zero padding included, kept current by the
+// optimiser kernels (OptArgs::img / img_idx) and rebuilt by dcv_mlp_set_params
+__global__ __launch_bounds__(256) void snet_pack_kernel(const float* __restrict__ params, const int* __restrict__ idx, int64_t n, float* __restrict__ img) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int j = idx[i];
+        if (j >= 0) img[j] = params[i];
+    }
+}
+bool snet_image_build(dcv_mlp* m) {
+    static const bool off = [] { const char* e = getenv("DCV_SNET_IMG"); return e && e[0] == '0'; }();
+    if (off) return false;
+    if (m->snet_img != nullptr) return true;
+    SnetLayer ly[DCV_MAX_LAYERS];
+    std::vector<int2> tab;
+    std::vector<int> idx;
+    int fl = 0;
+    int64_t per_wg = 0;
+    if (!snet_layout(m, ly, tab, nullptr, fl, per_wg, &idx)) return false;
+    for (int l = 0; l < m->L; ++l)   // 16-byte copies: every image row must start on a 16-byte boundary (pws and pout are multiples of 4)
+        if ((ly[l].lw & 3) || (ly[l].lb & 3)) return false;
+    float* img = nullptr;
+    int* didx = nullptr;
+    const size_t fpad = ((size_t)fl + 255) / 256 * 256;
+    if (hipMalloc(reinterpret_cast<void**>(&img), fpad * sizeof(float)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&didx), idx.size() * sizeof(int)) != hipSuccess ||
+        hipMemset(img, 0, fpad * sizeof(float)) != hipSuccess ||
+        hipMemcpy(didx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipGetLastError();
+        if (img) (void)hipFree(img);
+        if (didx) (void)hipFree(didx);
+        return false;
+    }
+    m->snet_img = img;
+    m->snet_img_idx = didx;
+    m->snet_img_floats = fl;
+    if (snet_image_repack(m, nullptr) != DCV_OK || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipGetLastError();
+        snet_image_free(m);
+        return false;
+    }
+    return true;
+}
+int snet_image_repack(dcv_mlp* m, hipStream_t s) {
+    if (m->snet_img == nullptr) return DCV_OK;
+    int64_t blocks = cdiv(m->n_params, 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(snet_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)m->params, (const int*)m->snet_img_idx, m->n_params, m->snet_img);
+    DCV_CHECK_LAUNCH();
+    return DCV_OK;
+}
+void snet_image_free(dcv_mlp* m) {
+    if (m->snet_img) (void)hipFree(m->snet_img);
+    if (m->snet_img_idx) (void)hipFree(m->snet_img_idx);
+    m->snet_img = nullptr;
+    m->snet_img_idx = nullptr;
+    m->snet_img_floats = 0;
 }
 
 void snet_free(dcv_mlp* m) {
@@ -449,6 +517,8 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
         }
     }
     a.params = m->params;
+    a.img = m->snet_img;
+    a.img_floats = m->snet_img_floats;
     a.Xn = Xn_d;
     a.ld = ld;
     a.rows = rm;

@@ -37,6 +37,9 @@ struct SnetDtArgs {
     int ps[DCV_MAX_LAYERS + 1];
     int act_len;                  // floats of the activation region [lh[0], lh[0] + act_len): the blob of a workgroup
     const float* params;
+    const float* img;             // global weight image in the LDS layout (snet.hip: snet_image_build), or null: table-driven staging
+    int img_floats;               //   floats of the whole image; the backward stages [img_bwd0, img_floats): layers >= 1
+    int img_bwd0;
     const float* Xn;
     int64_t ld;
     RowMap rows;                  // half = batch: logical row p < B is x_t of pair p, row B + p its x_lag
@@ -118,49 +121,54 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
         for (int u = 0; u < XA; ++u) xv[u] = load_x(u);
     };
     // ---- stage every weight image and bias (snet.hip: one flat table, twelve loads in flight, two dependent round trips)
-    // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
-    // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
-    int2 e[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-        const int i = t + NT * u;
-        e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-    }
-    for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
-        float4 v[12];
-#pragma unroll
+    if (a.img != nullptr) {   // one contiguous LDS-DMA copy of the weight image (kept current by the optimiser), the input rows behind it
+        snet_stage_image<NT>(a.img, sl, 0, a.img_floats, t);
+    } else {
+        // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
+        // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
+        int2 e[12];
+    #pragma unroll
         for (int u = 0; u < 12; ++u) {
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e[u].x >= 0) {
-                const float* src = a.params + e[u].x;
-                const int nv = (e[u].y >> 20) & 7;
-                if ((e[u].y >> 24) & 1) {
-                    v[u] = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v[u].x = src[0];
-                    if (nv > 1) v[u].y = src[1];
-                    if (nv > 2) v[u].z = src[2];
-                    if (nv > 3) v[u].w = src[3];
+            const int i = t + NT * u;
+            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
+        for (int i0 = t; i0 < a.stage_n; i0 += 12 * NT) {
+            float4 v[12];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e[u].x >= 0) {
+                    const float* src = a.params + e[u].x;
+                    const int nv = (e[u].y >> 20) & 7;
+                    if ((e[u].y >> 24) & 1) {
+                        v[u] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v[u].x = src[0];
+                        if (nv > 1) v[u].y = src[1];
+                        if (nv > 2) v[u].z = src[2];
+                        if (nv > 3) v[u].w = src[3];
+                    }
                 }
             }
+            if (x_vec && !x_issued) {   // the rows of X ride along the data round trip
+                x_issued = true;
+                issue_x();
+            }
+            int2 en[12];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int i = i0 + 12 * NT + NT * u;
+                en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+            }
+    #pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) e[u] = en[u];
         }
-        if (x_vec && !x_issued) {   // the rows of X ride along the data round trip
-            x_issued = true;
-            issue_x();
-        }
-        int2 en[12];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = i0 + 12 * NT + NT * u;
-            en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-        }
-#pragma unroll
-        for (int u = 0; u < 12; ++u)
-            if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) e[u] = en[u];
     }
     if (x_vec && !x_issued) issue_x();
+    if (a.img != nullptr) vm_wait<0>();   // this wave's image copies have landed (the barrier below covers the other waves)
     asm volatile("" ::"s"(ka_touch));
     if (x_vec) {
 #pragma unroll
@@ -334,51 +342,56 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
             }
         }
     };
-    // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
-    // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
-    int2 e[12];
-#pragma unroll
-    for (int u = 0; u < 12; ++u) {
-        const int i = a.stage_bwd0 + t + NT * u;
-        e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-    }
-    for (int i0 = a.stage_bwd0 + t; i0 < a.stage_n; i0 += 12 * NT) {
-        float4 v[12];
-        if (!blob_issued) {
-            blob_issued = true;
-            issue_blob();
-        }
-#pragma unroll
+    if (a.img != nullptr) {   // layers >= 1 of the weight image by LDS-DMA, the blob's first units behind it
+        snet_stage_image<NT>(a.img, sl, a.img_bwd0, a.img_floats, t);
+    } else {
+        // the table entries of pass p + 1 are requested behind the data loads of pass p and arrive in the same round trip: one
+        // dependent round trip per pass (+ the first table read) instead of two (round 4: 8 -> 5 for the C2 network's four passes)
+        int2 e[12];
+    #pragma unroll
         for (int u = 0; u < 12; ++u) {
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e[u].x >= 0) {
-                const float* src = a.params + e[u].x;
-                const int nv = (e[u].y >> 20) & 7;
-                if ((e[u].y >> 24) & 1) {
-                    v[u] = *reinterpret_cast<const float4*>(src);
-                } else {
-                    v[u].x = src[0];
-                    if (nv > 1) v[u].y = src[1];
-                    if (nv > 2) v[u].z = src[2];
-                    if (nv > 3) v[u].w = src[3];
+            const int i = a.stage_bwd0 + t + NT * u;
+            e[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+        }
+        for (int i0 = a.stage_bwd0 + t; i0 < a.stage_n; i0 += 12 * NT) {
+            float4 v[12];
+            if (!blob_issued) {
+                blob_issued = true;
+                issue_blob();
+            }
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e[u].x >= 0) {
+                    const float* src = a.params + e[u].x;
+                    const int nv = (e[u].y >> 20) & 7;
+                    if ((e[u].y >> 24) & 1) {
+                        v[u] = *reinterpret_cast<const float4*>(src);
+                    } else {
+                        v[u].x = src[0];
+                        if (nv > 1) v[u].y = src[1];
+                        if (nv > 2) v[u].z = src[2];
+                        if (nv > 3) v[u].w = src[3];
+                    }
                 }
             }
+            if (!head_ran) run_head();   // this wave's table, blob and data loads are in flight
+            int2 en[12];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int i = i0 + 12 * NT + NT * u;
+                en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
+            }
+    #pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
+    #pragma unroll
+            for (int u = 0; u < 12; ++u) e[u] = en[u];
         }
-        if (!head_ran) run_head();   // this wave's table, blob and data loads are in flight
-        int2 en[12];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) {
-            const int i = i0 + 12 * NT + NT * u;
-            en[u] = i < a.stage_n ? a.stage_tab[i] : make_int2(-1, -1);
-        }
-#pragma unroll
-        for (int u = 0; u < 12; ++u)
-            if (e[u].y >= 0) *reinterpret_cast<float4*>(sl + (e[u].y & 0xFFFFF)) = v[u];
-#pragma unroll
-        for (int u = 0; u < 12; ++u) e[u] = en[u];
     }
     if (!blob_issued) issue_blob();
     if (!head_ran) run_head();
+    if (a.img != nullptr) vm_wait<0>();   // (the blob loads above are covered too)
     if (!a.fused.on && t < NG) s_g[t] = a.gradp[t];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -590,6 +603,7 @@ static bool snet_dt_build(dcv_mlp* m) {
     int tab_begin[DCV_MAX_LAYERS];
     if (!snet_layout(m, a.l, tab, tab_begin, fl, per_wg)) { delete pl; return false; }
     pl->per_wg = per_wg;
+    (void)snet_image_build(m);   // on failure the kernels keep the table-driven staging
     pl->fl = fl;
     {
         SnetDtArgs tmp = a;
@@ -679,6 +693,9 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
     if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)a.act_len)) return 1;
     a.params = m->params;
+    a.img = m->snet_img;
+    a.img_floats = m->snet_img_floats;
+    a.img_bwd0 = m->L > 1 ? a.l[1].lw : m->snet_img_floats;
     a.Xn = Xn_d;
     a.ld = ld;
     a.rows = RowMap{idx_d, row0, batch, m->desc.lag};
@@ -737,6 +754,9 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head,
         ra->bstride[l] = y.pb_stride;
     }
     a.params = m->params;
+    a.img = m->snet_img;
+    a.img_floats = m->snet_img_floats;
+    a.img_bwd0 = m->L > 1 ? a.l[1].lw : m->snet_img_floats;
     a.B = batch;
     a.blob = pl->blob;
     a.blob_stride = a.act_len;

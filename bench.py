@@ -172,6 +172,12 @@ class Fit:
 
     def validation_pass(self):
         eng = self.eng
+        if self.dist is None and self.val_steps > 1:   # as the calculator's _validate does: the whole pass in one call
+            if self.shuffled:
+                eng.eval_steps(self.Xn, self.lb, self.val_steps, idx=self.val_idx)
+            else:
+                eng.eval_steps(self.Xn, self.lb, self.val_steps, row0=self.n_train)
+            return
         for j in range(self.val_steps):
             if self.shuffled:
                 idx = self.val_idx[j * self.lb:(j + 1) * self.lb]
@@ -389,9 +395,12 @@ def run_c2(a, steps, warmup, cpu_seconds):
     def train_step(i):
         eng.train_step(Xn, row0=(i % spe) * bs, batch=bs)
 
-    def validation():
-        for j in range(val_steps):
-            eng.eval_step(Xn, row0=n_train + j * bs, batch=bs)
+    def validation():   # as the calculator's _validate does: the whole pass in one call (one launch for this network)
+        if val_steps > 1:
+            eng.eval_steps(Xn, bs, val_steps, row0=n_train)
+        else:
+            for j in range(val_steps):
+                eng.eval_step(Xn, row0=n_train + j * bs, batch=bs)
 
     eng.reset_log(2 * (steps + warmup + 64) + (steps // spe + 2) * (val_steps + 1))
     for i in range(30 + warmup):

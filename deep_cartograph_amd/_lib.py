@@ -105,6 +105,7 @@ SIGNATURES = {
     "dcv_mlp_layer_output": (C.c_int, [_P, _I32, _I64, _P, _P]),
     "dcv_mlp_train_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_eval_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
+    "dcv_mlp_eval_steps": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "dcv_mlp_log_width": (_I32, [_P]),
     "dcv_mlp_reset_log": (C.c_int, [_P, _I32, _P]),
     "dcv_mlp_read_log": (C.c_int, [_P, _P, _I32, C.POINTER(_I32), _P]),
@@ -154,8 +155,8 @@ def load():
         fn.restype = res
         fn.argtypes = args
     ver = lib.dcv_abi_version()
-    if ver != 4:
-        raise DcvError(f"libdcv.so ABI version {ver}, expected 4 (rebuild: make -C deep_cartograph_amd/csrc)")
+    if ver != 5:
+        raise DcvError(f"libdcv.so ABI version {ver}, expected 5 (rebuild: make -C deep_cartograph_amd/csrc)")
     _lib = lib
     return lib
 

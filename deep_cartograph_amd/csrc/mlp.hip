@@ -2481,6 +2481,58 @@ extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, cons
     });
 }
 
+// nbatches consecutive evaluation steps -- batch j = samples [j * batch, (j + 1) * batch) of the index list (idx_d + j * batch)
+// or of the row range (row0 + j * batch) -- with one loss record each, in batch order: the records dcv_mlp_eval_step would
+// append one call at a time.  A small network (snet.hip / snet_dt.hip) evaluates up to kEvalBatchesPerLaunch batches per
+// launch -- a validation pass is then one launch instead of one (autoencoder) or one (Deep-TICA) per batch, each of which is
+// mostly launch latency and weight staging; every other engine runs the steps one after the other.
+extern "C" int dcv_mlp_eval_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int32_t nbatches,
+                                  void* stream) {
+    DCV_REQUIRE(m && Xn_d, "dcv_mlp_eval_steps: null argument");
+    DCV_REQUIRE(nbatches >= 0, "dcv_mlp_eval_steps: nbatches=%d", nbatches);
+    DCV_REQUIRE(batch >= 1 && batch <= m->desc.max_batch, "dcv_mlp_eval_steps: batch=%d exceeds max_batch=%d", batch, m->desc.max_batch);
+    DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_eval_steps: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
+    DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp_eval_steps: call dcv_mlp_reset_log first");
+    hipStream_t s = as_stream(stream);
+    constexpr int kEvalBatchesPerLaunch = 64;
+    constexpr int64_t kEvalWorkgroupsPerLaunch = 4096;
+    int32_t j = 0;
+    while (j < nbatches) {
+        const int64_t off = (int64_t)j * batch;
+        const int64_t* idx_j = idx_d ? idx_d + off : nullptr;
+        const int64_t row_j = idx_d ? row0 : row0 + off;
+        int nb = nbatches - j < kEvalBatchesPerLaunch ? nbatches - j : kEvalBatchesPerLaunch;
+        int rc = 1;
+        if (nb > 1 && !m->any_drop && !m->any_bn && !prof_on(m, 0)) {   // (a profiled run samples single steps)
+            g_launch_ev = LaunchEvents{};
+            if (m->desc.model == DCV_MODEL_AE && !(m->snet_tried && m->snet == nullptr)) {
+                const int64_t per = cdiv((int64_t)batch, 16);   // (an upper bound of the workgroups per batch: tiles of >= 16 rows)
+                while (nb > 1 && per * nb > kEvalWorkgroupsPerLaunch) --nb;
+                if (nb > 1) rc = snet_ae_step(m, Xn_d, ld, RowMap{idx_j, row_j, 0, 0}, batch, batch, 0, nullptr, s, true, nb);
+                if (rc == DCV_OK) m->last_path = 1;
+            } else if (m->desc.model == DCV_MODEL_DEEPTICA && !(m->snet_dt_tried && m->snet_dt == nullptr)) {
+                const int64_t per = cdiv((int64_t)batch, 16);
+                while (nb > 1 && per * nb > kEvalWorkgroupsPerLaunch) --nb;
+                if (nb > 1) rc = snet_dt_forward(m, Xn_d, ld, idx_j, row_j, batch, 2, false, s, nb);
+                if (rc == DCV_OK) m->last_path = 2;
+            }
+            if (rc < 0) return rc;
+            if (rc == DCV_OK) {
+                m->fwd_train = false;
+                m->head_done = m->desc.model == DCV_MODEL_DEEPTICA;
+                m->snet_fwd_valid = false;
+                m->last_batch = batch;
+                j += nb;
+                continue;
+            }
+        }
+        rc = dcv_mlp_eval_step(m, Xn_d, ld, idx_j, row_j, batch, stream);
+        if (rc) return rc;
+        j += 1;
+    }
+    return DCV_OK;
+}
+
 // ---- data-parallel step: the whole sequence behind one entry point, the collectives through a host callback
 namespace {
 struct DpTrampoline {

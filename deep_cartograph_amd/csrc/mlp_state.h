@@ -110,7 +110,7 @@ struct ReduceArgsView {
 // snet.hip: the whole autoencoder step in one launch when the network fits in LDS; 1 = not applicable
 // R rows of this rank, `batch` = the GLOBAL batch (loss scale 2 / (batch * F)); write_log = false: the caller logs (after an all-reduce)
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
-                 hipStream_t s, bool write_log = true);
+                 hipStream_t s, bool write_log = true, int nb = 1);   // nb > 1: that many evaluation batches of R rows in one launch
 void snet_free(dcv_mlp* m);
 // the weight image both fused small-network plans stage from (snet.hip); repack: after the parameters were written by anyone
 // but the optimiser (dcv_mlp_set_params)
@@ -118,8 +118,9 @@ bool snet_image_build(dcv_mlp* m);
 int snet_image_repack(dcv_mlp* m, hipStream_t s);
 void snet_image_free(dcv_mlp* m);
 // snet_dt.hip: Deep-TICA forward (+ statistics, + loss head) and backward of a network that fits in LDS; 1 = not applicable
+// nb > 1 (head == 2, no blob): that many evaluation batches of `batch` pairs in one launch, batch j = the pairs [j * batch, (j + 1) * batch)
 int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
-                    hipStream_t s);
+                    hipStream_t s, int nb = 1);
 int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s);
 void snet_dt_free(dcv_mlp* m);
 // bn.hip

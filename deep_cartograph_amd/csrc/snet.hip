@@ -35,7 +35,8 @@ struct SnetArgs {
     const float* Xn;
     int64_t ld;
     RowMap rows;
-    int64_t R;
+    int64_t R;                    // rows of one batch
+    int nb, wgpb;                 // batches of this launch (> 1: evaluation only, snet_ae_eval_batches) and workgroups per batch
     const float* range;
     float scale;                  // 2 / (global batch * F)
     int train;
@@ -78,7 +79,16 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
     // ---- input tile H_0 (rows past the batch: zeros): with 16-byte loads the whole tile is at most four units per thread
     //      (TR * pin / 4 <= 4 * NT); they are issued inside the weight staging, behind its data loads, and written to LDS
     //      after it
-    const int64_t r0 = (int64_t)blockIdx.x * TR;
+    // workgroup -> (batch of the launch, tile of the batch): one batch unless this is a batched evaluation (nb > 1), whose
+    // batch j covers the logical rows [j * R, (j + 1) * R) of the row map
+    const int bj = a.nb > 1 ? (int)blockIdx.x / a.wgpb : 0;
+    const int tile0 = (int)blockIdx.x - bj * a.wgpb;
+    const int64_t r0 = (int64_t)tile0 * TR;
+    RowMap rows = a.rows;
+    if (bj != 0) {
+        if (rows.idx != nullptr) rows.idx += (int64_t)bj * a.R;
+        rows.row0 += (int64_t)bj * a.R;
+    }
     const int F0 = a.l[0].in, p0 = a.l[0].pin, ps0 = a.ps[0];
     float* H0 = sl + a.lh[0];
     const bool x_vec = (F0 & 3) == 0 && (a.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Xn) & 15) == 0;
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                 for (int u = 0; u < 4; ++u) {
                     const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
                     xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + a.rows.template get<true>(r0 + r) * a.ld + 4 * c);
+                    if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + rows.template get<true>(r0 + r) * a.ld + 4 * c);
                 }
             }
             int2 en[12];
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
         for (int u = 0; u < 4; ++u) {
             const int i = t + NT * u, r = i >> x_sh, c = i - (r << x_sh);
             xv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + a.rows.template get<true>(r0 + r) * a.ld + 4 * c);
+            if (i < x_tot && r0 + r < a.R && c < f4) xv[u] = *reinterpret_cast<const float4*>(a.Xn + rows.template get<true>(r0 + r) * a.ld + 4 * c);
         }
     }
     asm volatile("" ::"s"(ka_touch));   // the touches have landed
@@ -164,7 +174,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
         for (int i = t; i < TR * p0; i += NT) {
             const int r = i / p0, c = i - r * p0;
             float v = 0.f;
-            if (r0 + r < a.R && c < F0) v = a.Xn[a.rows.template get<true>(r0 + r) * a.ld + c];
+            if (r0 + r < a.R && c < F0) v = a.Xn[rows.template get<true>(r0 + r) * a.ld + c];
             H0[r * ps0 + c] = v;
         }
     }
@@ -316,21 +326,35 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
     // ---- last workgroup: total squared error in block order, loss record
     unsigned* flag = reinterpret_cast<unsigned*>(sl + a.lred);
     __syncthreads();
-    if (!handoff_arrive_last(a.ticket, gridDim.x, flag)) return;
+    const unsigned wgpb = a.nb > 1 ? (unsigned)a.wgpb : gridDim.x;
+    if (!handoff_arrive_last(a.ticket + bj, wgpb, flag)) return;
     SNET_STAMP(61);
     if (t < 64) {
         double tot = 0.0;
-        for (int b0 = t; b0 < (int)gridDim.x; b0 += 64) tot += handoff_load(a.sse_part + b0);
+        const double* sp = a.sse_part + (int64_t)bj * wgpb;
+        for (int b0 = t; b0 < (int)wgpb; b0 += 64) tot += handoff_load(sp + b0);
         for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
         if (t == 0) {
-            a.stats[0] = tot;
+            if (a.nb <= 1) a.stats[0] = tot;
             if (a.log != nullptr) {   // (a data-parallel step logs after the all-reduce of the sum: ae_log_kernel)
-                const int slot = *a.log_count;
+                // a batched evaluation appends its records in batch order: every batch's last arriver reads the counter, the last
+                // of those (a second ticket, taken behind the read) moves it
+                const int slot0 = *a.log_count;
+                const int slot = slot0 + bj;
                 if (slot < a.log_cap) {
                     a.log[(int64_t)slot * a.log_width + 0] = tot / (a.Bg * (double)a.l[0].in);
                     a.log[(int64_t)slot * a.log_width + 1] = a.Bg;
                 }
-                *a.log_count = slot + 1;
+                if (a.nb <= 1) {
+                    *a.log_count = slot + 1;
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0) ; the counter has been read" ::: "memory");
+                    const unsigned prev = __hip_atomic_fetch_add(a.ticket + a.nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev == (unsigned)a.nb - 1u) {
+                        __hip_atomic_store(a.ticket + a.nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *a.log_count = slot0 + a.nb;
+                    }
+                }
             }
         }
     }
@@ -345,6 +369,10 @@ struct SnetPlan {
     int64_t per_wg;      // floats of one workgroup's partials over all layers (dense: sum out * in + out)
     unsigned long long* stamps;   // 64 words, or null (DCV_SNET_STAMPS=1)
     int2* stage_tab;     // device copy of the staging table
+    double* ev_sse;      // batched evaluation: squared-error partials [batches][workgroups per batch] ...
+    int64_t ev_sse_n;
+    unsigned* ev_ticket; // ... and one ticket per batch + the one that moves the log counter (zero between launches)
+    int64_t ev_ticket_n;
 };
 
 // Builds the plan once per engine.  Not applicable (returns false): wide layers, dropout, a network that does not fit
@@ -392,6 +420,10 @@ static bool snet_build(dcv_mlp* m) {
             pl->part = nullptr;
             pl->part_floats = 0;
             pl->stamps = nullptr;
+            pl->ev_sse = nullptr;
+            pl->ev_sse_n = 0;
+            pl->ev_ticket = nullptr;
+            pl->ev_ticket_n = 0;
             {
                 const char* e = getenv("DCV_SNET_STAMPS");
                 if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void**>(&pl->stamps), 64 * sizeof(unsigned long long)) == hipSuccess)
@@ -470,6 +502,8 @@ void snet_free(dcv_mlp* m) {
     if (pl->part) (void)hipFree(pl->part);
     if (pl->stamps) (void)hipFree(pl->stamps);
     if (pl->stage_tab) (void)hipFree(pl->stage_tab);
+    if (pl->ev_sse) (void)hipFree(pl->ev_sse);
+    if (pl->ev_ticket) (void)hipFree(pl->ev_ticket);
     delete pl;
     m->snet = nullptr;
 }
@@ -477,8 +511,10 @@ void snet_free(dcv_mlp* m) {
 // One fused step of the autoencoder over `R` rows (train != 0: gradient partials are left for the reduction, whose
 // descriptors are filled into `ra`).  Returns 1 when the fused form does not apply (the caller takes the layer-by-layer
 // path), DCV_OK when the launch was enqueued.
+// nb > 1 (evaluation only): nb batches of R rows each in the one launch -- batch j = the logical rows [j * R, (j + 1) * R) of
+// `rm` -- with one loss record per batch, appended in batch order.
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
-                 hipStream_t s, bool write_log) {
+                 hipStream_t s, bool write_log, int nb) {
     static const int64_t kMaxPartBytes = 96ll << 20;
     if (m->snet == nullptr) {
         if (m->snet_tried || !snet_build(m)) {
@@ -488,8 +524,38 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
         m->snet_tried = true;
     }
     SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
-    const int64_t nwg = cdiv(R, pl->TR);
-    if (nwg > m->spart_blocks || nwg * pl->per_wg * (int64_t)sizeof(float) > kMaxPartBytes || nwg > 512) return 1;   // large batches: the tiled products are the better engine
+    const int64_t wgpb = cdiv(R, pl->TR);
+    if (wgpb > m->spart_blocks || wgpb * pl->per_wg * (int64_t)sizeof(float) > kMaxPartBytes || wgpb > 512) return 1;   // large batches: the tiled products are the better engine
+    if (nb < 1 || (nb > 1 && (train || !write_log))) return 1;
+    const int64_t nwg = wgpb * nb;
+    if (nb > 1) {
+        if (pl->ev_sse_n < nwg) {
+            if (pl->ev_sse) (void)hipFree(pl->ev_sse);
+            pl->ev_sse = nullptr;
+            pl->ev_sse_n = 0;
+            if (hipMalloc(reinterpret_cast<void**>(&pl->ev_sse), (size_t)nwg * sizeof(double)) != hipSuccess) {
+                (void)hipGetLastError();
+                return 1;
+            }
+            pl->ev_sse_n = nwg;
+        }
+        if (pl->ev_ticket_n < nb + 1) {
+            if (pl->ev_ticket) (void)hipFree(pl->ev_ticket);
+            pl->ev_ticket = nullptr;
+            pl->ev_ticket_n = 0;
+            const int64_t cap = nb + 1 < 256 ? 256 : nb + 1;
+            // (hipMemsetAsync on the launch stream: ordered before the launch below, and an earlier batched launch on the stream
+            // has left its tickets at zero)
+            if (hipMalloc(reinterpret_cast<void**>(&pl->ev_ticket), (size_t)cap * sizeof(unsigned)) != hipSuccess ||
+                hipMemsetAsync(pl->ev_ticket, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {
+                (void)hipGetLastError();
+                if (pl->ev_ticket) (void)hipFree(pl->ev_ticket);
+                pl->ev_ticket = nullptr;
+                return 1;
+            }
+            pl->ev_ticket_n = cap;
+        }
+    }
     const int64_t part_need = nwg * pl->per_wg + 8 * (int64_t)m->L;   // + the alignment padding of the items
     if (train && pl->part_floats < part_need) {
         if (pl->part) (void)hipFree(pl->part);
@@ -523,12 +589,14 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     a.ld = ld;
     a.rows = rm;
     a.R = R;
+    a.nb = nb;
+    a.wgpb = (int)wgpb;
     a.range = m->feat_range;
     a.scale = (float)(2.0 / ((double)batch * (double)m->desc.dims[0]));
     a.train = train;
     a.part = pl->part;
-    a.sse_part = m->spart;
-    a.ticket = m->ticket;
+    a.sse_part = nb > 1 ? pl->ev_sse : m->spart;
+    a.ticket = nb > 1 ? pl->ev_ticket : m->ticket;
     a.stats = m->stats;
     a.Bg = (double)batch;
     a.log = write_log ? m->log : nullptr;

@@ -44,6 +44,7 @@ struct SnetDtArgs {
     int64_t ld;
     RowMap rows;                  // half = batch: logical row p < B is x_t of pair p, row B + p its x_lag
     int B;                        // pairs of this rank's batch
+    int nb, wgpb;                 // batches of this launch (> 1: evaluation with the fused head only) and workgroups per batch
     int d;                        // network outputs (<= 4)
     int store_blob;
     float* blob;                  // [workgroups][blob_stride]
@@ -83,13 +84,22 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
     __shared__ TicaWaveLdsAny s_head;
     __shared__ double s_stat[40];
     __shared__ unsigned s_flag;
+    __shared__ int s_slot;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int rg = wave % RG, cg = wave / RG;
     const int q = lane >> 4, n = lane & 15;
     const int L = a.L;
     const unsigned ka_touch = touch_kernargs<(int)sizeof(SnetDtArgs)>();
     // ---- input tile: local row r is pair p0 + r % HP, half r / HP
-    const int64_t p0 = (int64_t)blockIdx.x * HP;
+    // workgroup -> (batch of the launch, tile of the batch); batch j of a batched evaluation = the pairs [j * B, (j + 1) * B)
+    const int bj = a.nb > 1 ? (int)blockIdx.x / a.wgpb : 0;
+    const unsigned wgpb = a.nb > 1 ? (unsigned)a.wgpb : gridDim.x, wg0 = (unsigned)bj * wgpb;
+    const int64_t p0 = (int64_t)(blockIdx.x - wg0) * HP;
+    RowMap rows = a.rows;
+    if (bj != 0) {
+        if (rows.idx != nullptr) rows.idx += (int64_t)bj * a.B;
+        rows.row0 += (int64_t)bj * a.B;
+    }
     const int F0 = a.l[0].in, pin0 = a.l[0].pin, ps0 = a.ps[0];
     float* H0 = sl + a.lh[0];
     const bool x_vec = (F0 & 3) == 0 && (a.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.Xn) & 15) == 0;
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
     auto src_row = [&](int r) -> int64_t {   // matrix row of local row r, -1 past the batch
         const int half = r >= HP ? 1 : 0;
         const int64_t p = p0 + (r - half * HP);
-        return p < a.B ? a.rows.template get<true>(half ? (int64_t)a.B + p : p) : -1;
+        return p < a.B ? rows.template get<true>(half ? (int64_t)a.B + p : p) : -1;
     };
     constexpr int XA = XU < 8 ? XU : 8;   // units that ride along the weight staging; the rest (TR = 128) in a second batch
     float4 xv[XA];
@@ -247,23 +257,24 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
         }
     }
     // ---- last workgroup: the partials in block order, then the d x d loss head
-    if (!handoff_arrive_last(a.ticket, gridDim.x, &s_flag)) return;
+    if (!handoff_arrive_last(a.ticket + bj, wgpb, &s_flag)) return;
     {
         const int G = NT / W;
         double* s_grp = reinterpret_cast<double*>(sl);   // [G][W]: the weight images are dead
         const int g = t / W, o = t - g * W;
         if (g < G) {
             double s = 0.0;
-            for (unsigned b0 = g; b0 < gridDim.x; b0 += 8 * G) {   // eight loads in flight, added in block order
+            const double* sp = a.spart + (int64_t)wg0 * W;
+            for (unsigned b0 = g; b0 < wgpb; b0 += 8 * G) {   // eight loads in flight, added in block order
                 double v[8];
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
                     const unsigned b = b0 + (unsigned)u * G;
-                    v[u] = handoff_load(a.spart + (int64_t)(b < gridDim.x ? b : b0) * W + o);
+                    v[u] = handoff_load(sp + (int64_t)(b < wgpb ? b : b0) * W + o);
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    if (b0 + (unsigned)u * G < gridDim.x) s += v[u];
+                    if (b0 + (unsigned)u * G < wgpb) s += v[u];
             }
             s_grp[g * W + o] = s;
         }
@@ -271,18 +282,40 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a)
         if (t < W) {
             double s = 0.0;
             for (int g2 = 0; g2 < G; ++g2) s += s_grp[g2 * W + t];
-            a.stats[t] = s;
+            if (a.nb <= 1) a.stats[t] = s;
             s_stat[t] = s;
         }
         if (a.fused.on) {
             __syncthreads();
             if (wave == 0) {
                 const FusedHead& f = a.fused;
+                // a batched evaluation appends its records in batch order: the head of batch j writes record (counter + j) -- it is
+                // handed a log base moved by j records and a private copy of the counter -- and the last head to finish (a second
+                // ticket, taken behind its read of the counter) moves the counter by nb
+                double* logp = f.log;
+                int* lc = f.log_count;
+                int cap = f.log_cap, slot0 = 0;
+                if (a.nb > 1) {
+                    slot0 = *f.log_count;
+                    asm volatile("s_waitcnt vmcnt(0) ; the counter has been read" ::: "memory");
+                    if (lane == 0) s_slot = slot0;
+                    wave_sync_lds();
+                    logp = f.log + (int64_t)bj * f.log_width;
+                    lc = &s_slot;
+                    cap = f.log_cap - bj;
+                }
                 switch (D) {
-                    case 1: tica_grad_wave<1>(s_head.h1, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
-                    case 2: tica_grad_wave<2>(s_head.h2, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
-                    case 3: tica_grad_wave<3>(s_head.h3, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
-                    default: tica_grad_wave<4>(s_head.h4, s_stat, f.Bg, f.reg, f.gradp, f.log, f.log_count, f.log_cap, f.log_width, lane); break;
+                    case 1: tica_grad_wave<1>(s_head.h1, s_stat, f.Bg, f.reg, f.gradp, logp, lc, cap, f.log_width, lane); break;
+                    case 2: tica_grad_wave<2>(s_head.h2, s_stat, f.Bg, f.reg, f.gradp, logp, lc, cap, f.log_width, lane); break;
+                    case 3: tica_grad_wave<3>(s_head.h3, s_stat, f.Bg, f.reg, f.gradp, logp, lc, cap, f.log_width, lane); break;
+                    default: tica_grad_wave<4>(s_head.h4, s_stat, f.Bg, f.reg, f.gradp, logp, lc, cap, f.log_width, lane); break;
+                }
+                if (a.nb > 1 && lane == 0) {
+                    const unsigned prev = __hip_atomic_fetch_add(a.ticket + a.nb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (prev == (unsigned)a.nb - 1u) {
+                        __hip_atomic_store(a.ticket + a.nb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        *f.log_count = slot0 + a.nb;
+                    }
                 }
             }
         }
@@ -547,6 +580,8 @@ struct SnetDtPlan {
     int64_t blob_floats;
     double* spart;         // statistics partials
     int64_t spart_n;
+    unsigned* ev_ticket;   // batched evaluation: one ticket per batch + the one that moves the log counter (zero between launches)
+    int64_t ev_ticket_n;
     int64_t last_wg;       // workgroups and tile rows of the last forward (the backward launches the same grid)
     int last_tr;
 };
@@ -629,6 +664,7 @@ void snet_dt_free(dcv_mlp* m) {
     if (pl->part) (void)hipFree(pl->part);
     if (pl->blob) (void)hipFree(pl->blob);
     if (pl->spart) (void)hipFree(pl->spart);
+    if (pl->ev_ticket) (void)hipFree(pl->ev_ticket);
     if (pl->stage_tab) (void)hipFree(pl->stage_tab);
     delete pl;
     m->snet_dt = nullptr;
@@ -672,8 +708,9 @@ static int snet_dt_launch(K kern, int slot, size_t lds_bytes, const SnetDtArgs& 
 // Fused forward of one Deep-TICA batch (+ batch statistics, + the loss head when head != 0: 1 = training, the head's
 // matrices go to m->gradp; 2 = evaluation).  keep_blob: a backward may follow.  Returns 1 when the fused form does not
 // apply (the caller runs the layer-by-layer path), DCV_OK when the launch was enqueued.
+// nb > 1 (head == 2, no blob): nb batches of `batch` pairs each in the one launch, one loss record per batch in batch order.
 int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
-                    hipStream_t s) {
+                    hipStream_t s, int nb) {
     static const int64_t kMaxBytes = 64ll << 20;
     if (m->snet_dt == nullptr) {
         if (m->snet_dt_tried || !snet_dt_build(m)) {
@@ -687,10 +724,23 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     if (TR == 0) return 1;
     SnetDtArgs a = pl->base;
     const size_t lds_bytes = (size_t)snet_dt_map(a, pl->fl, TR) * sizeof(float);
-    const int64_t nwg = cdiv(batch, TR / 2);
+    const int64_t wgpb = cdiv(batch, TR / 2);
     const int W = m->stats_len;
-    if (nwg > 512 || nwg * pl->per_wg * (int64_t)sizeof(float) > kMaxBytes || nwg * a.act_len * (int64_t)sizeof(float) > kMaxBytes) return 1;
+    if (wgpb > 512 || wgpb * pl->per_wg * (int64_t)sizeof(float) > kMaxBytes || wgpb * a.act_len * (int64_t)sizeof(float) > kMaxBytes) return 1;
+    if (nb < 1 || (nb > 1 && (head != 2 || keep_blob))) return 1;
+    const int64_t nwg = wgpb * nb;
     if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
+    if (nb > 1 && pl->ev_ticket_n < nb + 1) {
+        const int64_t cap = nb + 1 < 256 ? 256 : nb + 1;
+        if (!grow(&pl->ev_ticket, &pl->ev_ticket_n, cap)) return 1;
+        if (hipMemsetAsync(pl->ev_ticket, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {   // in stream order, ahead of the launch below
+            (void)hipGetLastError();
+            (void)hipFree(pl->ev_ticket);
+            pl->ev_ticket = nullptr;
+            pl->ev_ticket_n = 0;
+            return 1;
+        }
+    }
     if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)a.act_len)) return 1;
     a.params = m->params;
     a.img = m->snet_img;
@@ -700,17 +750,19 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     a.ld = ld;
     a.rows = RowMap{idx_d, row0, batch, m->desc.lag};
     a.B = batch;
+    a.nb = nb;
+    a.wgpb = (int)wgpb;
     a.store_blob = keep_blob ? 1 : 0;
     a.blob = pl->blob;
     a.blob_stride = a.act_len;
     a.spart = pl->spart;
-    a.ticket = m->ticket;
+    a.ticket = nb > 1 ? pl->ev_ticket : m->ticket;
     a.stats = m->stats;
     a.fused = FusedHead{0, 0.0, 0.0, nullptr, nullptr, nullptr, 0, 0};
     if (head) a.fused = FusedHead{1, (double)batch, m->desc.tica_reg, head == 1 ? m->gradp : nullptr, m->log, m->log_count, m->log_cap, m->log_width};
     a.gradp = nullptr;
     a.part = nullptr;
-    pl->last_wg = nwg;
+    pl->last_wg = nb > 1 ? -1 : nwg;   // (no backward behind a batched evaluation)
     pl->last_tr = TR;
     switch (TR) {
         case 32: return snet_dt_launch(snet_dt_fwd_kernel<32>, 0, lds_bytes, a, nwg, s);

@@ -883,7 +883,8 @@ class NonLinear(CVCalculator):
         if self.shuffle:
             idx = idx[torch.randperm(len(idx))]
         bs = batch_size if batch_size > 0 else len(idx)
-        return [("idx", idx[i:i + bs].to(dev)) for i in range(0, len(idx), bs)]
+        idx_d = idx.to(dev).contiguous()   # one copy per epoch; the batches are consecutive views of it (third field: the whole list)
+        return [("idx", idx_d[i:i + bs], idx_d) for i in range(0, len(idx), bs)]
 
     @staticmethod
     def _part_len(part) -> int:
@@ -902,6 +903,22 @@ class NonLinear(CVCalculator):
             (self.engine.train_step if train else self.engine.eval_step)(Xn, **kw)
             return
         self.engine.data_parallel_step(Xn, self.comm._dist, global_batch_of(n), train=train, group=self.comm.group, **kw)
+
+    def _validate(self, Xn, vb, global_batch_of):
+        """The validation pass: one evaluation step per batch of the loader.  On one GPU the full-sized batches go down in ONE
+        call (dcv_mlp_eval_steps: small networks are evaluated many batches per launch) and the ragged last batch follows;
+        the records are those of the step-by-step loop, bit for bit."""
+        size = lambda b: int(b[1].numel()) if b[0] == "idx" else int(b[2])
+        k = 0
+        if not self.comm.active and len(vb) > 1:
+            while k < len(vb) and size(vb[k]) == size(vb[0]):
+                k += 1
+            if vb[0][0] == "idx":
+                self.engine.eval_steps(Xn, size(vb[0]), k, idx=vb[0][2])
+            else:
+                self.engine.eval_steps(Xn, size(vb[0]), k, row0=vb[0][1])
+        for b in vb[k:]:
+            self._step(Xn, b, False, global_batch_of)
 
     def _records_to_metrics(self, rec: np.ndarray):
         """(weighted mean loss, weighted mean eigenvalues or None, TICA buffers of the last record)."""
@@ -1026,8 +1043,7 @@ class NonLinear(CVCalculator):
                 self._step(Xn_train, b, True, gb)
                 if sched is not None:
                     sched.after_step()
-            for b in vb:
-                self._step(Xn_val, b, False, gb)
+            self._validate(Xn_val, vb, gb)
             rec = self.engine.read_log()   # the only host sync of the epoch
             if not np.all(np.isfinite(rec[:, 0])):
                 raise FloatingPointError("non-finite loss (ill-conditioned batch covariance?)")

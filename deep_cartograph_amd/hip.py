@@ -682,6 +682,17 @@ class Mlp:
         batch = int(batch if batch is not None else idx.numel())
         check(self.lib.dcv_mlp_eval_step(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_eval_step")
 
+    def eval_steps(self, Xn, batch: int, nbatches: int, idx=None, row0=0):
+        """A validation pass: `nbatches` evaluation steps of `batch` samples, batch j = idx[j * batch:(j + 1) * batch] (or rows
+        row0 + j * batch ...), one loss record each in batch order -- the records `nbatches` eval_step calls would append.
+        Small networks run many batches per launch (dcv_mlp_eval_steps, include/dcv.h)."""
+        batch, nbatches = int(batch), int(nbatches)
+        if idx is not None and idx.numel() < batch * nbatches:
+            raise DcvError(f"eval_steps: {idx.numel()} indices for {nbatches} batches of {batch}")
+        if idx is None and int(row0) + batch * nbatches > Xn.shape[0]:
+            raise DcvError(f"eval_steps: rows {row0} + {nbatches} x {batch} exceed the matrix ({Xn.shape[0]} rows)")
+        check(self.lib.dcv_mlp_eval_steps(self.h, *self._args(Xn, idx, row0, batch), nbatches, _stream()), "dcv_mlp_eval_steps")
+
     # -- metrics log
     def reset_log(self, capacity: int):
         check(self.lib.dcv_mlp_reset_log(self.h, int(capacity), _stream()), "dcv_mlp_reset_log")

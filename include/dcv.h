@@ -39,7 +39,7 @@ extern "C" {
 #define DCV_ESTATE (-4)  /* call order violated */
 #define DCV_ECALLBACK (-5) /* a host callback of the caller reported failure */
 
-#define DCV_ABI_VERSION 4
+#define DCV_ABI_VERSION 5
 
 int dcv_abi_version(void);
 const char* dcv_last_error(void);
@@ -307,6 +307,14 @@ int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t*
 /* Convenience for one GPU: forward + backward(train=0). */
 int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
                       int32_t batch, void* stream);
+/* A validation pass (the reference's Lightning validation loop over the DictLoader, cv_calculator.py:1456-1553 via
+ * trainer.fit): `nbatches` evaluation steps of `batch` samples each, batch j = idx_d[j * batch, (j + 1) * batch) -- or the
+ * rows row0 + [j * batch, (j + 1) * batch) when idx_d is null -- appending the nbatches loss records dcv_mlp_eval_step
+ * would append, in batch order, bit for bit.  Networks small enough for the fused kernels (dcv_mlp_last_path 1 / 2) are
+ * evaluated many batches per launch; the others step by step.  A ragged last batch is a separate dcv_mlp_eval_step.
+ * dcv_mlp_stats() is unspecified afterwards. */
+int dcv_mlp_eval_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
+                       int32_t batch, int32_t nbatches, void* stream);
 
 /* Test hook: keep / (1 - p) multipliers (0 or 1 / (1 - p)) that the dropout behind Linear `layer` applies to
  * rows [0, rows) of the batch matrix in training step number `step` (0-based count of training forwards since

@@ -27,7 +27,7 @@ def test_library_exports_every_header_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/dcv.h but not exported by libdcv.so"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
-    assert lib.dcv_abi_version() == 4
+    assert lib.dcv_abi_version() == 5
 
 
 def test_no_cpu_fallback():
@@ -95,10 +95,23 @@ def test_handoff_isa_order(tmp_path):
     kernels = _device_disassembly(tmp_path)
     assert len(kernels) > 200
     is_store = lambda s: s.startswith(("global_store", "buffer_store", "flat_store", "scratch_store"))
-    ticketed = {}
+    ticketed, elections = {}, {}
     for name, ins in kernels.items():
         for i, s in enumerate(ins):
             if not (re.match(r"global_atomic_add\s", s) and " sc0" in s):   # a returning add = a ticket
+                continue
+            if not any(x.startswith("global_load") and " sc1" in x for x in ins[i + 1:]):
+                # An ELECTION, not a hand-off: the batched validation pass of the fused small-network kernels ends every batch
+                # on a second ticket that only picks the workgroup that moves the log counter by the number of batches.  Nothing
+                # is handed over inside the launch behind it (the records are read by later launches / the host), so there is
+                # no payload to publish and nothing to acquire; what it needs is that each taker has READ the counter first:
+                # an s_waitcnt vmcnt(0) between the last load ahead of it and the add.
+                assert re.search(r"snet_ae_kernel|snet_dt_fwd_kernel", name), f"{name}: a ticket with no sc1 load behind it"
+                j = i - 1
+                while j >= 0 and not ins[j].startswith(("global_load", "flat_load", "buffer_load")):
+                    j -= 1
+                assert any(x.startswith("s_waitcnt") and "vmcnt(0)" in x for x in ins[j:i]), f"{name}: the election ticket does not wait for the counter read"
+                elections[name] = elections.get(name, 0) + 1
                 continue
             # ---- producer side: ... stores ; s_waitcnt vmcnt(0) ; s_barrier ; (no store) ; ticket -- and the payload
             # (the partials handed over in-launch) written with sc1 stores somewhere ahead of that wait.  Plain stores
@@ -132,6 +145,7 @@ def test_handoff_isa_order(tmp_path):
             assert inv and wait_after_inv and barrier_after, f"{name}: acquire / wait / barrier order behind the ticket is wrong"
             ticketed[name] = ticketed.get(name, 0) + 1
     names = " ".join(ticketed)
+    assert all(v == 1 and ticketed.get(k, 0) >= 1 for k, v in elections.items()) and len(elections) == 5, elections   # AE TR 32 / 16, Deep-TICA TR 32 / 64 / 128
     assert "ae_sse_kernel" in names
     for d in (1, 2, 3, 4):
         assert f"tica_stats_rows_kernelILi{d}E" in names

@@ -199,3 +199,64 @@ def test_fused_data_parallel_step_equals_the_single_process_step(model):
     assert len(_OneRank.calls) == 5 * 2 + 1     # statistics + gradients per training step, statistics for the evaluation step
     for e in engs:
         e.close()
+
+
+@pytest.mark.parametrize("model,dims,batch,nb,gather", [
+    ("deep_tica", [54, 16, 8, 2], 128, 5, True),      # the reference's network: 8 tiles per batch
+    ("deep_tica", [54, 15, 15, 2], 1000, 7, False),   # a ragged last tile in every batch, consecutive rows
+    ("deep_tica", [20, 7, 1], 37, 70, True),          # more batches than one launch takes (64): two launches
+    ("ae", [54, 16, 8, 2], 128, 5, True),
+    ("ae", [128, 64, 32, 2], 1000, 9, False),         # BASELINE C2's network
+    ("ae", [33, 12, 3], 77, 66, True),
+    ("deep_tica", [256, 512, 256, 3], 300, 3, True),  # too wide for the fused kernels: the entry point steps batch by batch
+])
+def test_batched_validation_pass_equals_step_by_step(model, dims, batch, nb, gather):
+    """dcv_mlp_eval_steps: the records of nb evaluation steps from one call (small networks: many batches per launch),
+    bit for bit those of nb dcv_mlp_eval_step calls, appended behind what the log already holds."""
+    from deep_cartograph_amd import hip
+
+    lag = 3
+    n = batch * nb + 50
+    X = ar_features(n + lag, dims[0], 5)
+    Xn, _, _ = normalized(X)
+    Xd = torch.from_numpy(Xn).cuda()
+    torch.manual_seed(1)
+    if model == "deep_tica":
+        full = dims
+        acts = ["tanh"] * (len(dims) - 2) + [None]
+        eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6)
+    else:
+        full = dims + dims[-2::-1]
+        acts = (["tanh"] * (len(dims) - 2) + [None]) * 2
+        eng = hip.Mlp("ae", full, acts, max_batch=batch)
+        eng.set_feature_range(np.ones(dims[0], dtype=np.float32))
+    push_params(eng, [torch.nn.Linear(full[i], full[i + 1]) for i in range(len(full) - 1)])
+    idx = torch.randperm(n)[:batch * nb].contiguous().cuda() if gather else None
+    # a log too short for the pass (the engine's first, 3 records): the records that fit are kept
+    eng.reset_log(3)
+    eng.eval_steps(Xd, batch, nb, idx=idx, row0=0 if gather else 7)
+    c = eng.read_log()
+    # step by step, behind one record so that the batched call starts at a non-zero counter
+    def one_by_one():
+        eng.reset_log(nb + 1)
+        eng.eval_step(Xd, **(dict(idx=idx[:batch]) if gather else dict(row0=7, batch=batch)))
+        for j in range(nb):
+            kw = dict(idx=idx[j * batch:(j + 1) * batch]) if gather else dict(row0=7 + j * batch, batch=batch)
+            eng.eval_step(Xd, **kw)
+        return eng.read_log()
+    a = one_by_one()
+    eng.reset_log(nb + 1)
+    eng.eval_step(Xd, **(dict(idx=idx[:batch]) if gather else dict(row0=7, batch=batch)))
+    eng.eval_steps(Xd, batch, nb, idx=idx, row0=0 if gather else 7)
+    b = eng.read_log()
+    assert a.shape == b.shape == (nb + 1, eng.log_width)
+    assert np.isfinite(a).all()
+    assert len(np.unique(a[1:, 0])) == nb            # the batches do differ
+    assert np.array_equal(a, b)
+    assert np.array_equal(c, a[1:4])
+    if dims[1] <= 64:
+        assert eng.last_path() == (2 if model == "deep_tica" else 1)
+    # and a training step still follows a batched pass
+    eng.reset_log(2)
+    eng.train_step(Xd, **(dict(idx=idx[:batch]) if gather else dict(row0=7, batch=batch)))
+    assert np.isfinite(eng.read_log()).all()

@@ -2494,8 +2494,6 @@ extern "C" int dcv_mlp_eval_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, con
     DCV_REQUIRE(ld >= m->desc.dims[0], "dcv_mlp_eval_steps: ld=%lld < F=%d", (long long)ld, m->desc.dims[0]);
     DCV_REQUIRE(m->log && m->log_cap > 0, "dcv_mlp_eval_steps: call dcv_mlp_reset_log first");
     hipStream_t s = as_stream(stream);
-    constexpr int kEvalBatchesPerLaunch = 64;
-    constexpr int64_t kEvalWorkgroupsPerLaunch = 4096;
     int32_t j = 0;
     while (j < nbatches) {
         const int64_t off = (int64_t)j * batch;

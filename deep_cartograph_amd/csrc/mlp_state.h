@@ -107,6 +107,11 @@ struct ReduceArgsView {
     int bblocks[DCV_MAX_LAYERS];
     int64_t wstride[DCV_MAX_LAYERS], bstride[DCV_MAX_LAYERS];   // floats between consecutive partials (multiples of 4)
 };
+// a batched validation pass (dcv_mlp_eval_steps) of a fused small-network engine: at most this many batches / workgroups per launch
+// (the plans allocate their per-batch tickets and per-workgroup partials for these bounds when they are built: no allocation
+// lands in a timed validation pass)
+constexpr int kEvalBatchesPerLaunch = 64;
+constexpr int64_t kEvalWorkgroupsPerLaunch = 4096;
 // snet.hip: the whole autoencoder step in one launch when the network fits in LDS; 1 = not applicable
 // R rows of this rank, `batch` = the GLOBAL batch (loss scale 2 / (batch * F)); write_log = false: the caller logs (after an all-reduce)
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,

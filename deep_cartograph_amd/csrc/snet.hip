@@ -424,6 +424,16 @@ static bool snet_build(dcv_mlp* m) {
             pl->ev_sse_n = 0;
             pl->ev_ticket = nullptr;
             pl->ev_ticket_n = 0;
+            // batched validation passes: partials and tickets for the bounds of dcv_mlp_eval_steps (33 KB); without them the
+            // passes go batch by batch
+            if (hipMalloc(reinterpret_cast<void**>(&pl->ev_sse), (size_t)kEvalWorkgroupsPerLaunch * sizeof(double)) == hipSuccess &&
+                hipMalloc(reinterpret_cast<void**>(&pl->ev_ticket), (size_t)(kEvalBatchesPerLaunch + 1) * sizeof(unsigned)) == hipSuccess &&
+                hipMemset(pl->ev_ticket, 0, (size_t)(kEvalBatchesPerLaunch + 1) * sizeof(unsigned)) == hipSuccess) {
+                pl->ev_sse_n = kEvalWorkgroupsPerLaunch;
+                pl->ev_ticket_n = kEvalBatchesPerLaunch + 1;
+            } else {
+                (void)hipGetLastError();
+            }
             {
                 const char* e = getenv("DCV_SNET_STAMPS");
                 if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void**>(&pl->stamps), 64 * sizeof(unsigned long long)) == hipSuccess)
@@ -528,34 +538,7 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     if (wgpb > m->spart_blocks || wgpb * pl->per_wg * (int64_t)sizeof(float) > kMaxPartBytes || wgpb > 512) return 1;   // large batches: the tiled products are the better engine
     if (nb < 1 || (nb > 1 && (train || !write_log))) return 1;
     const int64_t nwg = wgpb * nb;
-    if (nb > 1) {
-        if (pl->ev_sse_n < nwg) {
-            if (pl->ev_sse) (void)hipFree(pl->ev_sse);
-            pl->ev_sse = nullptr;
-            pl->ev_sse_n = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&pl->ev_sse), (size_t)nwg * sizeof(double)) != hipSuccess) {
-                (void)hipGetLastError();
-                return 1;
-            }
-            pl->ev_sse_n = nwg;
-        }
-        if (pl->ev_ticket_n < nb + 1) {
-            if (pl->ev_ticket) (void)hipFree(pl->ev_ticket);
-            pl->ev_ticket = nullptr;
-            pl->ev_ticket_n = 0;
-            const int64_t cap = nb + 1 < 256 ? 256 : nb + 1;
-            // (hipMemsetAsync on the launch stream: ordered before the launch below, and an earlier batched launch on the stream
-            // has left its tickets at zero)
-            if (hipMalloc(reinterpret_cast<void**>(&pl->ev_ticket), (size_t)cap * sizeof(unsigned)) != hipSuccess ||
-                hipMemsetAsync(pl->ev_ticket, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {
-                (void)hipGetLastError();
-                if (pl->ev_ticket) (void)hipFree(pl->ev_ticket);
-                pl->ev_ticket = nullptr;
-                return 1;
-            }
-            pl->ev_ticket_n = cap;
-        }
-    }
+    if (nb > 1 && (nwg > pl->ev_sse_n || nb + 1 > pl->ev_ticket_n)) return 1;   // (sized by snet_build for the bounds of dcv_mlp_eval_steps)
     const int64_t part_need = nwg * pl->per_wg + 8 * (int64_t)m->L;   // + the alignment padding of the items
     if (train && pl->part_floats < part_need) {
         if (pl->part) (void)hipFree(pl->part);

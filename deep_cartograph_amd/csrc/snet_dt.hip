@@ -624,6 +624,20 @@ static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
     return best;
 }
 
+template <class T>
+static bool grow(T** p, int64_t* have, int64_t need) {
+    if (*have >= need) return true;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    if (hipMalloc(reinterpret_cast<void**>(p), (size_t)need * sizeof(T)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    *have = need;
+    return true;
+}
+
 static bool snet_dt_build(dcv_mlp* m) {
     if (m->desc.model != DCV_MODEL_DEEPTICA || m->any_drop || m->any_bn || m->d_out > 4 || m->d_out < 1 || snet_disabled()) return false;
     SnetDtPlan* pl = new (std::nothrow) SnetDtPlan();
@@ -654,6 +668,16 @@ static bool snet_dt_build(dcv_mlp* m) {
     a.stage_tab = pl->stage_tab;
     a.stage_n = (int)tab.size();
     a.stage_bwd0 = m->L > 1 ? tab_begin[1] : (int)tab.size();
+    // batched validation passes: statistics partials and tickets for the bounds of dcv_mlp_eval_steps, allocated now so that no
+    // allocation lands in a timed pass (without them the passes go batch by batch)
+    if (grow(&pl->spart, &pl->spart_n, kEvalWorkgroupsPerLaunch * (int64_t)m->stats_len) && grow(&pl->ev_ticket, &pl->ev_ticket_n, (int64_t)kEvalBatchesPerLaunch + 1)) {
+        if (hipMemset(pl->ev_ticket, 0, (size_t)pl->ev_ticket_n * sizeof(unsigned)) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(pl->ev_ticket);
+            pl->ev_ticket = nullptr;
+            pl->ev_ticket_n = 0;
+        }
+    }
     m->snet_dt = pl;
     return true;
 }
@@ -668,20 +692,6 @@ void snet_dt_free(dcv_mlp* m) {
     if (pl->stage_tab) (void)hipFree(pl->stage_tab);
     delete pl;
     m->snet_dt = nullptr;
-}
-
-template <class T>
-static bool grow(T** p, int64_t* have, int64_t need) {
-    if (*have >= need) return true;
-    if (*p) (void)hipFree(*p);
-    *p = nullptr;
-    *have = 0;
-    if (hipMalloc(reinterpret_cast<void**>(p), (size_t)need * sizeof(T)) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    *have = need;
-    return true;
 }
 
 template <class K>
@@ -730,18 +740,7 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     if (nb < 1 || (nb > 1 && (head != 2 || keep_blob))) return 1;
     const int64_t nwg = wgpb * nb;
     if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
-    if (nb > 1 && pl->ev_ticket_n < nb + 1) {
-        const int64_t cap = nb + 1 < 256 ? 256 : nb + 1;
-        if (!grow(&pl->ev_ticket, &pl->ev_ticket_n, cap)) return 1;
-        if (hipMemsetAsync(pl->ev_ticket, 0, (size_t)cap * sizeof(unsigned), s) != hipSuccess) {   // in stream order, ahead of the launch below
-            (void)hipGetLastError();
-            (void)hipFree(pl->ev_ticket);
-            pl->ev_ticket = nullptr;
-            pl->ev_ticket_n = 0;
-            return 1;
-        }
-    }
-    if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)a.act_len)) return 1;
+    if (nb > 1 && nb + 1 > pl->ev_ticket_n) return 1;   // (sized by snet_dt_build for the bounds of dcv_mlp_eval_steps)
     a.params = m->params;
     a.img = m->snet_img;
     a.img_floats = m->snet_img_floats;

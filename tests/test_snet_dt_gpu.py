@@ -228,7 +228,7 @@ def test_batched_validation_pass_equals_step_by_step(model, dims, batch, nb, gat
     else:
         full = dims + dims[-2::-1]
         acts = (["tanh"] * (len(dims) - 2) + [None]) * 2
-        eng = hip.Mlp("ae", full, acts, max_batch=batch)
+        eng = hip.Mlp("ae", full, acts, max_batch=batch, latent_layer=len(dims) - 1)
         eng.set_feature_range(np.ones(dims[0], dtype=np.float32))
     push_params(eng, [torch.nn.Linear(full[i], full[i + 1]) for i in range(len(full) - 1)])
     idx = torch.randperm(n)[:batch * nb].contiguous().cuda() if gather else None

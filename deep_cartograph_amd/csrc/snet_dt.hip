@@ -741,6 +741,7 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     const int64_t nwg = wgpb * nb;
     if (!grow(&pl->spart, &pl->spart_n, nwg * W)) return 1;
     if (nb > 1 && nb + 1 > pl->ev_ticket_n) return 1;   // (sized by snet_dt_build for the bounds of dcv_mlp_eval_steps)
+    if (keep_blob && !grow(&pl->blob, &pl->blob_floats, nwg * (int64_t)a.act_len)) return 1;
     a.params = m->params;
     a.img = m->snet_img;
     a.img_floats = m->snet_img_floats;
@@ -751,7 +752,7 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     a.B = batch;
     a.nb = nb;
     a.wgpb = (int)wgpb;
-    a.store_blob = keep_blob ? 1 : 0;
+    a.store_blob = keep_blob && pl->blob != nullptr ? 1 : 0;
     a.blob = pl->blob;
     a.blob_stride = a.act_len;
     a.spart = pl->spart;

@@ -170,6 +170,38 @@ class Fit:
         else:   # statistics all-reduce, then the gradient all-reduce of the upper layers under the layer-0 weight gradient
             eng.data_parallel_step(self.Xn, self.step_comm, self.gb, row0=r0, batch=self.lb, train=True)
 
+    def train_run(self, i, count):
+        """Steps i .. i + count - 1 (within one epoch): one dcv_mlp_train_steps call on one GPU -- the epoch loop behind the C-ABI,
+        as the calculator's fit runs it when no scheduler steps in between -- else step by step."""
+        j = i % self.steps_per_epoch
+        assert j + count <= self.steps_per_epoch
+        if self.dist is not None or count == 1:
+            for k in range(count):
+                self.train_step(i + k)
+            return
+        if self.shuffled:
+            if j == 0 or self.epoch_idx is None:
+                self._epoch_start()
+            self.eng.train_steps(self.Xn, self.lb, count, idx=self.epoch_idx[j * self.lb:])
+        else:
+            self.eng.train_steps(self.Xn, self.lb, count, row0=j * self.lb)
+
+    @staticmethod
+    def runs(steps, picked, steps_per_epoch):
+        """The timed steps as (first step, count, sampled) runs: a sampled step stands alone, the unsampled ones between two
+        sampled steps (and up to an epoch's end: the validation pass follows there) are one run."""
+        i = 0
+        while i < steps:
+            if i in picked:
+                yield i, 1, True
+                i += 1
+                continue
+            j = i + 1
+            while j < steps and j not in picked and j % steps_per_epoch != 0:
+                j += 1
+            yield i, j - i, False
+            i = j
+
     def validation_pass(self):
         eng = self.eng
         if self.dist is None and self.val_steps > 1:   # as the calculator's _validate does: the whole pass in one call
@@ -235,11 +267,11 @@ class Fit:
             eng.profile_begin(len(picked) + 1, 1)
         t0 = time.perf_counter()
         self.val_timed = 0
-        for i in range(steps):
+        for i, count, sampled in self.runs(steps, picked, self.steps_per_epoch):
             if picked:
-                eng.profile_pause(i not in picked, picked.get(i, ()))
-            self.train_step(i)
-            if with_validation and (i + 1) % self.steps_per_epoch == 0:
+                eng.profile_pause(not sampled, picked.get(i, ()))
+            self.train_run(i, count)
+            if with_validation and (i + count) % self.steps_per_epoch == 0:
                 self.validation_pass()
                 self.val_timed += self.val_steps
         self.barrier()
@@ -406,16 +438,20 @@ def run_c2(a, steps, warmup, cpu_seconds):
     for i in range(30 + warmup):
         train_step(i)
     torch.cuda.synchronize()
-    picked = {i: () for i in Fit.sample_plan(steps, a.profile_every)}   # one fused launch per step: both classes are that launch
+    # one fused launch per step (both classes are that launch): the plan's forward samples alone, every 8th step of a long run
+    picked = {i: () for i, skip in Fit.sample_plan(steps, a.profile_every).items() if "fwd" not in skip}
     if picked:
         eng.profile_begin(len(picked) + 1, 1)
     t0 = time.perf_counter()
     n_val = 0
-    for i in range(steps):
+    for i, count, sampled in Fit.runs(steps, picked, spe):   # the unsampled steps between two sampled ones: one dcv_mlp_train_steps call
         if picked:
-            eng.profile_pause(i not in picked)
-        train_step(i)
-        if (i + 1) % spe == 0:
+            eng.profile_pause(not sampled)
+        if count == 1:
+            train_step(i)
+        else:
+            eng.train_steps(Xn, bs, count, row0=(i % spe) * bs)
+        if (i + count) % spe == 0:
             validation()
             n_val += val_steps
     torch.cuda.synchronize()

@@ -106,6 +106,7 @@ SIGNATURES = {
     "dcv_mlp_train_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_eval_step": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _P]),
     "dcv_mlp_eval_steps": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32, _P]),
+    "dcv_mlp_train_steps": (C.c_int, [_P, _P, _I64, _P, _I64, _I32, _I32, _P]),
     "dcv_mlp_log_width": (_I32, [_P]),
     "dcv_mlp_reset_log": (C.c_int, [_P, _I32, _P]),
     "dcv_mlp_read_log": (C.c_int, [_P, _P, _I32, C.POINTER(_I32), _P]),

@@ -2481,6 +2481,23 @@ extern "C" int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, cons
     });
 }
 
+// nsteps consecutive training steps in one call: step j takes samples [j * batch, (j + 1) * batch) of the index list / the row
+// range, exactly as nsteps calls of dcv_mlp_train_step would (same launches, same records).  What it removes is the caller's
+// per-step cost: a small-network step is ~30 - 40 us of device time and a Python caller spends 10 - 30 us per call on some
+// hosts (bench.py c2: 46 us per step from Python against 39 us of launches) -- the epoch loop of a fit belongs on this side
+// of the boundary.
+extern "C" int dcv_mlp_train_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int32_t nsteps,
+                                   void* stream) {
+    DCV_REQUIRE(m && Xn_d, "dcv_mlp_train_steps: null argument");
+    DCV_REQUIRE(nsteps >= 0 && batch >= 1, "dcv_mlp_train_steps: nsteps=%d batch=%d", nsteps, batch);
+    for (int32_t j = 0; j < nsteps; ++j) {
+        const int64_t off = (int64_t)j * batch;
+        const int rc = dcv_mlp_train_step(m, Xn_d, ld, idx_d ? idx_d + off : nullptr, idx_d ? row0 : row0 + off, batch, stream);
+        if (rc) return rc;
+    }
+    return DCV_OK;
+}
+
 // nbatches consecutive evaluation steps -- batch j = samples [j * batch, (j + 1) * batch) of the index list (idx_d + j * batch)
 // or of the row range (row0 + j * batch) -- with one loss record each, in batch order: the records dcv_mlp_eval_step would
 // append one call at a time.  A small network (snet.hip / snet_dt.hip) evaluates up to kEvalBatchesPerLaunch batches per

@@ -904,21 +904,26 @@ class NonLinear(CVCalculator):
             return
         self.engine.data_parallel_step(Xn, self.comm._dist, global_batch_of(n), train=train, group=self.comm.group, **kw)
 
-    def _validate(self, Xn, vb, global_batch_of):
-        """The validation pass: one evaluation step per batch of the loader.  On one GPU the full-sized batches go down in ONE
-        call (dcv_mlp_eval_steps: small networks are evaluated many batches per launch) and the ragged last batch follows;
-        the records are those of the step-by-step loop, bit for bit."""
+    def _run_batches(self, Xn, batches, train: bool, global_batch_of, per_step=None):
+        """One pass over the loader's batches: a training step (train) or an evaluation step per batch.  On one GPU and with
+        nothing to do between steps (`per_step` None: no learning-rate scheduler) the full-sized batches go down in ONE call --
+        dcv_mlp_train_steps / dcv_mlp_eval_steps: the epoch loop runs behind the C-ABI, and small networks are evaluated many
+        batches per launch -- and the ragged last batch follows; launches, parameters and loss records are those of the
+        step-by-step loop, bit for bit."""
         size = lambda b: int(b[1].numel()) if b[0] == "idx" else int(b[2])
         k = 0
-        if not self.comm.active and len(vb) > 1:
-            while k < len(vb) and size(vb[k]) == size(vb[0]):
+        if not self.comm.active and per_step is None and len(batches) > 1:
+            while k < len(batches) and size(batches[k]) == size(batches[0]):
                 k += 1
-            if vb[0][0] == "idx":
-                self.engine.eval_steps(Xn, size(vb[0]), k, idx=vb[0][2])
+            many = self.engine.train_steps if train else self.engine.eval_steps
+            if batches[0][0] == "idx":
+                many(Xn, size(batches[0]), k, idx=batches[0][2])
             else:
-                self.engine.eval_steps(Xn, size(vb[0]), k, row0=vb[0][1])
-        for b in vb[k:]:
-            self._step(Xn, b, False, global_batch_of)
+                many(Xn, size(batches[0]), k, row0=batches[0][1])
+        for b in batches[k:]:
+            self._step(Xn, b, train, global_batch_of)
+            if per_step is not None:
+                per_step()
 
     def _records_to_metrics(self, rec: np.ndarray):
         """(weighted mean loss, weighted mean eigenvalues or None, TICA buffers of the last record)."""
@@ -1039,11 +1044,8 @@ class NonLinear(CVCalculator):
             do_val = (epoch + 1) % self.check_val_every_n_epoch == 0
             vb = self._batches(val_part, bs, dev) if do_val else []
             self.engine.reset_log(len(tb) + len(vb))
-            for b in tb:
-                self._step(Xn_train, b, True, gb)
-                if sched is not None:
-                    sched.after_step()
-            self._validate(Xn_val, vb, gb)
+            self._run_batches(Xn_train, tb, True, gb, per_step=sched.after_step if sched is not None else None)
+            self._run_batches(Xn_val, vb, False, gb)
             rec = self.engine.read_log()   # the only host sync of the epoch
             if not np.all(np.isfinite(rec[:, 0])):
                 raise FloatingPointError("non-finite loss (ill-conditioned batch covariance?)")

@@ -682,6 +682,16 @@ class Mlp:
         batch = int(batch if batch is not None else idx.numel())
         check(self.lib.dcv_mlp_eval_step(self.h, *self._args(Xn, idx, row0, batch), _stream()), "dcv_mlp_eval_step")
 
+    def train_steps(self, Xn, batch: int, nsteps: int, idx=None, row0=0):
+        """`nsteps` training steps in one call (constant learning rate): step j on idx[j * batch:(j + 1) * batch] (or rows
+        row0 + j * batch ...), identical to nsteps train_step calls -- the per-call cost of the host is paid once."""
+        batch, nsteps = int(batch), int(nsteps)
+        if idx is not None and idx.numel() < batch * nsteps:
+            raise DcvError(f"train_steps: {idx.numel()} indices for {nsteps} batches of {batch}")
+        if idx is None and int(row0) + batch * nsteps > Xn.shape[0]:
+            raise DcvError(f"train_steps: rows {row0} + {nsteps} x {batch} exceed the matrix ({Xn.shape[0]} rows)")
+        check(self.lib.dcv_mlp_train_steps(self.h, *self._args(Xn, idx, row0, batch), nsteps, _stream()), "dcv_mlp_train_steps")
+
     def eval_steps(self, Xn, batch: int, nbatches: int, idx=None, row0=0):
         """A validation pass: `nbatches` evaluation steps of `batch` samples, batch j = idx[j * batch:(j + 1) * batch] (or rows
         row0 + j * batch ...), one loss record each in batch order -- the records `nbatches` eval_step calls would append.

@@ -307,6 +307,12 @@ int dcv_mlp_train_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t*
 /* Convenience for one GPU: forward + backward(train=0). */
 int dcv_mlp_eval_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
                       int32_t batch, void* stream);
+/* The training part of an epoch (the reference's Lightning training loop over the DictLoader, cv_calculator.py:1456-1553 via
+ * trainer.fit) with a constant learning rate: `nsteps` training steps, step j on idx_d[j * batch, (j + 1) * batch) -- or the
+ * rows row0 + [j * batch, (j + 1) * batch) when idx_d is null -- identical in launches, parameters and loss records to
+ * nsteps calls of dcv_mlp_train_step; the caller's per-call cost is paid once. */
+int dcv_mlp_train_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0,
+                        int32_t batch, int32_t nsteps, void* stream);
 /* A validation pass (the reference's Lightning validation loop over the DictLoader, cv_calculator.py:1456-1553 via
  * trainer.fit): `nbatches` evaluation steps of `batch` samples each, batch j = idx_d[j * batch, (j + 1) * batch) -- or the
  * rows row0 + [j * batch, (j + 1) * batch) when idx_d is null -- appending the nbatches loss records dcv_mlp_eval_step

@@ -407,3 +407,12 @@ def test_bench_sampling_plan():
     every = bench.Fit.sample_plan(20, 1)
     assert sorted(every) == list(range(1, 20)) and all(skip == () for skip in every.values())
     assert bench.Fit.sample_plan(1, 0) == {0: ()}          # a one-step run has only that step
+    # the timed steps as runs: sampled steps alone, the unsampled ones between them as one dcv_mlp_train_steps call that never
+    # crosses an epoch's end (the validation pass follows there)
+    for steps, spe in ((20, 976), (400, 195), (7, 3), (2000, 976)):
+        picked = bench.Fit.sample_plan(steps, 0)
+        runs = list(bench.Fit.runs(steps, picked, spe))
+        assert [i for i, _, _ in runs] == [sum(c for _, c, _ in runs[:k]) for k in range(len(runs))] and sum(c for _, c, _ in runs) == steps
+        assert all((i % spe) + c <= spe for i, c, _ in runs)
+        assert all((c == 1 and i in picked) if sampled else not any(k in picked for k in range(i, i + c)) for i, c, sampled in runs)
+    assert max(c for _, c, _ in bench.Fit.runs(400, bench.Fit.sample_plan(400, 0), 195)) == 3

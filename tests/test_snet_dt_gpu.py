@@ -260,3 +260,47 @@ def test_batched_validation_pass_equals_step_by_step(model, dims, batch, nb, gat
     eng.reset_log(2)
     eng.train_step(Xd, **(dict(idx=idx[:batch]) if gather else dict(row0=7, batch=batch)))
     assert np.isfinite(eng.read_log()).all()
+
+
+@pytest.mark.parametrize("model,dims,batch,gather", [
+    ("deep_tica", [54, 16, 8, 2], 128, True),
+    ("ae", [54, 16, 8, 2], 100, False),
+    ("deep_tica", [256, 512, 3], 300, True),   # the layer-by-layer engine
+])
+def test_training_steps_in_one_call_equal_step_by_step(model, dims, batch, gather):
+    """dcv_mlp_train_steps: nsteps training steps behind one call -- parameters, optimiser state and loss records bit for bit
+    those of nsteps dcv_mlp_train_step calls."""
+    from deep_cartograph_amd import hip
+
+    lag, nsteps = 2, 6
+    n = batch * nsteps + 20
+    Xn, _, _ = normalized(ar_features(n + lag, dims[0], 9))
+    Xd = torch.from_numpy(Xn).cuda()
+    idx = torch.randperm(n)[:batch * nsteps].contiguous().cuda() if gather else None
+
+    def engine():
+        torch.manual_seed(2)
+        if model == "deep_tica":
+            full, acts = dims, ["tanh"] * (len(dims) - 2) + [None]
+            eng = hip.Mlp("deep_tica", dims, acts, max_batch=batch, lag=lag, tica_reg=1e-6, lr=1e-3)
+        else:
+            full, acts = dims + dims[-2::-1], (["tanh"] * (len(dims) - 2) + [None]) * 2
+            eng = hip.Mlp("ae", full, acts, max_batch=batch, latent_layer=len(dims) - 1, lr=1e-3)
+            eng.set_feature_range(np.ones(dims[0], dtype=np.float32))
+        push_params(eng, [torch.nn.Linear(full[i], full[i + 1]) for i in range(len(full) - 1)])
+        eng.reset_log(2 * nsteps)
+        return eng
+
+    a = engine()
+    for j in range(nsteps):
+        a.train_step(Xd, **(dict(idx=idx[j * batch:(j + 1) * batch]) if gather else dict(row0=3 + j * batch, batch=batch)))
+    b = engine()
+    b.train_steps(Xd, batch, nsteps, idx=idx, row0=0 if gather else 3)
+    ra, rb = a.read_log(), b.read_log()
+    assert ra.shape == (nsteps, a.log_width) and np.array_equal(ra, rb)
+    assert torch.equal(a.params_view(), b.params_view())
+    # and the next step continues from the same optimiser state
+    kw = dict(idx=idx[:batch]) if gather else dict(row0=3, batch=batch)
+    a.train_step(Xd, **kw)
+    b.train_step(Xd, **kw)
+    assert torch.equal(a.params_view(), b.params_view())

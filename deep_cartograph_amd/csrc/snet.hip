@@ -518,6 +518,18 @@ void snet_free(dcv_mlp* m) {
     m->snet = nullptr;
 }
 
+// Rows per workgroup of the fused autoencoder step (the plan is built on first use); 0: the fused form does not apply.
+int snet_ae_tile_rows(dcv_mlp* m) {
+    if (m->snet == nullptr) {
+        if (m->snet_tried || !snet_build(m)) {
+            m->snet_tried = true;
+            return 0;
+        }
+        m->snet_tried = true;
+    }
+    return static_cast<SnetPlan*>(m->snet)->TR;
+}
+
 // One fused step of the autoencoder over `R` rows (train != 0: gradient partials are left for the reduction, whose
 // descriptors are filled into `ra`).  Returns 1 when the fused form does not apply (the caller takes the layer-by-layer
 // path), DCV_OK when the launch was enqueued.
@@ -526,13 +538,7 @@ void snet_free(dcv_mlp* m) {
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
                  hipStream_t s, bool write_log, int nb) {
     static const int64_t kMaxPartBytes = 96ll << 20;
-    if (m->snet == nullptr) {
-        if (m->snet_tried || !snet_build(m)) {
-            m->snet_tried = true;
-            return 1;
-        }
-        m->snet_tried = true;
-    }
+    if (snet_ae_tile_rows(m) == 0) return 1;
     SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
     const int64_t wgpb = cdiv(R, pl->TR);
     if (wgpb > m->spart_blocks || wgpb * pl->per_wg * (int64_t)sizeof(float) > kMaxPartBytes || wgpb > 512) return 1;   // large batches: the tiled products are the better engine

@@ -1,5 +1,7 @@
 """Parity of the HIP MLP engine (Deep-TICA / autoencoder steps, training, inference) against
 the torch-CPU autograd oracle.  Run on the GPU box: python -m pytest tests -m gpu"""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -738,7 +740,17 @@ def test_launch_time_switches_leave_the_bits_alone(model, tmp_path):
     assert len(set(hashes.values())) == 1, hashes
 
 
-@pytest.mark.parametrize("seed", list(range(10)))
+def _fuzz_seeds():
+    """The ten seeds of the suite, plus a range for one-off sweeps: DCV_FUZZ_SEEDS=100:200 (profiles/r04_gpu_calls.log has the
+    sweeps that were run)."""
+    extra = os.environ.get("DCV_FUZZ_SEEDS", "")
+    if ":" in extra:
+        lo, hi = extra.split(":")
+        return list(range(10)) + list(range(int(lo), int(hi)))
+    return list(range(10))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_random_configurations_match_oracle(seed):
     """Random small configurations (widths 2..150 incl. odd ones, 1-3 hidden layers, batch 20..700, gathered or contiguous
     rows, both models, mixed activations): three SGD steps against the float32 autograd oracle.  Exercises whichever tile

@@ -80,3 +80,36 @@ def test_bench_refuses_more_rccl_ranks_than_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, text=True, timeout=300)
     assert p.returncode != 0 and "one device per rank" in p.stderr
+
+
+def test_bench_single_gpu_line_carries_every_block():
+    """The driver's form (`python bench.py --gpus 1 --steps K --warmup W`) on a small matrix: ONE JSON line with the contract
+    keys, `roofline` and `cpu_baseline`, and the round-4 blocks (`shuffled`, `large_batch`, `c2`, `ref_small`) -- with the
+    epoch loop issued as dcv_mlp_train_steps runs between the sampled steps and the validation passes as dcv_mlp_eval_steps."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "300000", "--batch", "4096", "--steps", "70", "--warmup", "3",
+            "--cpu-seconds", "1", "--large-batch", "65516", "--large-steps", "3", "--other-mode-steps", "4", "--shuffled-steps", "40",
+            "--c2-steps", "420", "--ref-small-steps", "12"]
+    p = subprocess.run(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 70 and line["warmup"] == 3 and line["vs_baseline"] is None and line["dtype"] == "f32"
+    assert abs(line["value"] - 4096 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    # 300 000 frames, lag 10, 80 % training pairs: 58 steps per epoch -> one validation pass inside the 70 timed steps
+    assert line["config"]["validation_steps_timed"] >= 1
+    r = line["roofline"]
+    assert r["bound"] == "mfma" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["rows_per_launch"] == 4096 + 10
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and line["value"] > 10 * cb["value"]
+    assert line["shuffled"]["value"] > 0 and line["shuffled"]["rows_per_launch"] == 2 * 4096
+    assert line["large_batch"]["global_batch"] == 65516 and line["large_batch"]["value"] > 0
+    c2 = line["c2"]
+    assert c2["value"] > 0 and c2["config"]["validation_steps_timed"] == 2 * c2["config"]["val_steps_per_epoch"] > 0   # 420 steps = two epochs of 195
+    assert c2["roofline"]["samples"] > 0
+    rs = line["ref_small"]["runs"]
+    assert len(rs) == 4 and all(x["fused_small_network_path"] and x["value"] > 0 for x in rs)

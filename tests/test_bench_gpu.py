@@ -113,3 +113,27 @@ def test_bench_single_gpu_line_carries_every_block():
     assert c2["roofline"]["samples"] > 0
     rs = line["ref_small"]["runs"]
     assert len(rs) == 4 and all(x["fused_small_network_path"] and x["value"] > 0 for x in rs)
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_bench_collective_path_on_real_rccl_world1(native):
+    """DCV_FORCE_DIST=1: the data-parallel branch of bench.py (dcv_mlp_dp_step, statistics and gradient all-reduces in stream
+    order with the kernels) over the REAL RCCL -- torch.distributed's `nccl` backend, or the library's own communicator with
+    --native-rccl -- as a one-rank group on the one GPU.  The closest rehearsal of the N > 1 run this box allows: RCCL
+    initialisation, its kernels between ours on the launch stream, the side-stream overlap of the upper layers' gradients."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["DCV_FORCE_DIST"] = "1"
+    env["MASTER_PORT"] = str(_free_port())
+    args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "300000", "--batch", "4096", "--steps", "12", "--warmup", "3",
+            "--no-cpu-baseline", "--large-batch", "0", "--other-mode-steps", "0", "--shuffled-steps", "6", "--c2-steps", "0", "--ref-small-steps", "0"]
+    if native:
+        args.append("--native-rccl")
+    p = subprocess.run(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["communicator_world_size"] == 1
+    ct = line["config"]["collective_timing"]
+    assert ct["statistics"]["us_per_allreduce"] > 0 and ct["gradients"]["us_per_allreduce"] > 0
+    assert -4.0 <= line["loss_last_train"] <= 0.0

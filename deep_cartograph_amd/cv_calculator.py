@@ -617,6 +617,57 @@ _OPTIMIZERS_REFUSED = {"LBFGS": "needs a closure that re-evaluates the model sev
 _IMPLEMENTATION_SWITCHES = ("foreach", "fused", "capturable", "differentiable")   # no effect on the arithmetic
 
 
+class _torch_threads:
+    """with _torch_threads(k): torch's intra-op thread count capped at k for the block (restored afterwards)."""
+
+    def __init__(self, k: int):
+        self.k = k
+
+    def __enter__(self):
+        self.prev = torch.get_num_threads()
+        if self.prev > self.k:
+            torch.set_num_threads(self.k)
+        return self
+
+    def __exit__(self, *exc):
+        if torch.get_num_threads() != self.prev:
+            torch.set_num_threads(self.prev)
+        return False
+
+
+class _Batches:
+    """The batches of one pass over a DictLoader, without the per-batch objects: kind 'idx' (base = the device index list of
+    the pass, batch i = base[i * bs:(i + 1) * bs]) or 'range' (base = first row, batch i = rows base + i * bs ...)."""
+
+    def __init__(self, kind: str, base, n: int, bs: int):
+        self.kind, self.base, self.n, self.bs = kind, base, int(n), int(bs)
+        self.count = (self.n + self.bs - 1) // self.bs if self.n > 0 else 0
+
+    def __len__(self):
+        return self.count
+
+    def size(self, i: int) -> int:
+        return min(self.bs, self.n - i * self.bs)
+
+    def full(self) -> int:
+        """Number of leading batches of the full size bs."""
+        return self.n // self.bs
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(self.count))]
+        if i < 0:
+            i += self.count
+        if not 0 <= i < self.count:
+            raise IndexError(i)
+        if self.kind == "idx":
+            return ("idx", self.base[i * self.bs:i * self.bs + self.size(i)], self.base)
+        return ("range", self.base + i * self.bs, self.size(i))
+
+    def __iter__(self):
+        return (self[i] for i in range(self.count))
+
+
 class _HostLRScheduler:
     """torch.optim.lr_scheduler.<name> (reference :1382-1394, adjusted by :1228-1273) evaluated on the host: the very
     torch class runs over a one-parameter optimiser of the configured type, and after each of its steps the
@@ -872,19 +923,25 @@ class NonLinear(CVCalculator):
 
     def _batches(self, part, batch_size: int, dev):
         """DictLoader: consecutive slices of batch_size, last partial batch kept, fresh randperm per
-        epoch when shuffling.  Yields ('idx', tensor) or ('range', row0, count)."""
+        epoch when shuffling.  A sequence of ('idx', tensor, whole list) or ('range', row0, count) entries, materialised on
+        access (an epoch of 10 000 batches issued by ONE dcv_mlp_train_steps call never builds 10 000 views)."""
         if isinstance(part, tuple):
             off, n = part
             if self.shuffle:
                 part = torch.arange(off, off + n)
             else:
-                return [("range", off + i, min(batch_size, n - i)) for i in range(0, n, batch_size if batch_size > 0 else n)]
+                return _Batches("range", off, n, batch_size if batch_size > 0 else n)
         idx = part
         if self.shuffle:
-            idx = idx[torch.randperm(len(idx))]
+            # the reference's permutation (global CPU generator); torch.randperm is a sequential algorithm whose result does not
+            # depend on the intra-op thread count, but with the 128 threads of a GPU host it takes 15 ms for 160 000 indices
+            # against 1.3 ms with 8 (thread start-up for its fill / copy loops)
+            with _torch_threads(8):
+                perm = torch.randperm(len(idx))
+            idx = idx[perm]
         bs = batch_size if batch_size > 0 else len(idx)
         idx_d = idx.to(dev).contiguous()   # one copy per epoch; the batches are consecutive views of it (third field: the whole list)
-        return [("idx", idx_d[i:i + bs], idx_d) for i in range(0, len(idx), bs)]
+        return _Batches("idx", idx_d, len(idx), bs)
 
     @staticmethod
     def _part_len(part) -> int:
@@ -910,22 +967,21 @@ class NonLinear(CVCalculator):
         dcv_mlp_train_steps / dcv_mlp_eval_steps: the epoch loop runs behind the C-ABI, and small networks are evaluated many
         batches per launch -- and the ragged last batch follows; launches, parameters and loss records are those of the
         step-by-step loop, bit for bit."""
-        size = lambda b: int(b[1].numel()) if b[0] == "idx" else int(b[2])
         k = 0
         if not self.comm.active and per_step is None and len(batches) > 1:
-            while k < len(batches) and size(batches[k]) == size(batches[0]):
-                k += 1
-            many = self.engine.train_steps if train else self.engine.eval_steps
-            if batches[0][0] == "idx":
-                many(Xn, size(batches[0]), k, idx=batches[0][2])
-            else:
-                many(Xn, size(batches[0]), k, row0=batches[0][1])
+            k = batches.full()
+            if k > 0:
+                many = self.engine.train_steps if train else self.engine.eval_steps
+                if batches.kind == "idx":
+                    many(Xn, batches.bs, k, idx=batches.base)
+                else:
+                    many(Xn, batches.bs, k, row0=batches.base)
         for b in batches[k:]:
             self._step(Xn, b, train, global_batch_of)
             if per_step is not None:
                 per_step()
 
-    def _records_to_metrics(self, rec: np.ndarray):
+    def _records_to_metrics(self, rec: np.ndarray, need_eig: bool = True):
         """(weighted mean loss, weighted mean eigenvalues or None, TICA buffers of the last record)."""
         w = rec[:, 1]
         loss = float((rec[:, 0] * w).sum() / w.sum())
@@ -1049,7 +1105,7 @@ class NonLinear(CVCalculator):
             rec = self.engine.read_log()   # the only host sync of the epoch
             if not np.all(np.isfinite(rec[:, 0])):
                 raise FloatingPointError("non-finite loss (ill-conditioned batch covariance?)")
-            train_loss, _, _ = self._records_to_metrics(rec[:len(tb)])
+            train_loss, _, _ = self._records_to_metrics(rec[:len(tb)], need_eig=False)   # (only validation logs eigenvalues)
             stop = False
             if do_val:
                 valid_loss, eig, buffers = self._records_to_metrics(rec[len(tb):])
@@ -1297,7 +1353,7 @@ class AECalculator(NonLinear):
     def n_val_samples_local(self) -> int:
         return self.validation_data.shape[0]
 
-    def _records_to_metrics(self, rec):
+    def _records_to_metrics(self, rec, need_eig: bool = True):
         w = rec[:, 1]
         return float((rec[:, 0] * w).sum() / w.sum()), None, None
 
@@ -1346,20 +1402,17 @@ class DeepTICACalculator(NonLinear):
     def n_val_samples_local(self) -> int:
         return self.validation_data.shape[0] - self.lag()  # create_timelagged_dataset(validation_data) (reference :2546-2553)
 
-    def _records_to_metrics(self, rec):
+    def _records_to_metrics(self, rec, need_eig: bool = True):
         d = self.cv_dimension
         w = rec[:, 1]
         loss = float((rec[:, 0] * w).sum() / w.sum())
+        if not need_eig:
+            return loss, None, None
         reg = float(self.configuration.get("tica_regularization", 1e-6))
-        evs = []
-        buffers = None
-        for r in rec:
-            C0 = r[2:2 + d * d].reshape(d, d)
-            Ct = r[2 + d * d:2 + 2 * d * d].reshape(d, d)
-            ev, evecs = linalg.tica_eigh(C0, Ct, reg=reg)
-            evs.append(ev)
-            buffers = (r[2 + 2 * d * d:2 + 2 * d * d + d].astype(np.float32), evecs.astype(np.float32))
-        eig = (np.array(evs) * w[:, None]).sum(axis=0) / w.sum()
+        # the d x d TICA of every record in one stacked pass (the same LAPACK routine per record as linalg.tica_eigh)
+        ev, evecs = linalg.tica_eigh_stack(rec[:, 2:2 + d * d].reshape(-1, d, d), rec[:, 2 + d * d:2 + 2 * d * d].reshape(-1, d, d), reg=reg)
+        buffers = (rec[-1, 2 + 2 * d * d:2 + 2 * d * d + d].astype(np.float32), evecs[-1].astype(np.float32))
+        eig = (ev * w[:, None]).sum(axis=0) / w.sum()
         return loss, eig, buffers   # buffers: TICA of the LAST batch (SURVEY.md Appendix A.6 ii)
 
     def to_torch_module(self):

@@ -416,3 +416,42 @@ def test_bench_sampling_plan():
         assert all((i % spe) + c <= spe for i, c, _ in runs)
         assert all((c == 1 and i in picked) if sampled else not any(k in picked for k in range(i, i + c)) for i, c, sampled in runs)
     assert max(c for _, c, _ in bench.Fit.runs(400, bench.Fit.sample_plan(400, 0), 195)) == 3
+
+
+def test_epoch_loop_host_helpers():
+    """The host side of an epoch (round 4: it was 70 - 95 % of a fit's wall time): the lazy batch list yields the DictLoader's
+    batches, the stacked d x d TICA equals the per-record one bit for bit, torch.randperm does not depend on the thread count
+    it is run under."""
+    from deep_cartograph_amd import linalg
+    from deep_cartograph_amd.cv_calculator import _Batches, _torch_threads
+
+    base = torch.arange(100, 1100)
+    b = _Batches("idx", base, 1000, 256)
+    assert len(b) == 4 and b.full() == 3 and [b.size(i) for i in range(4)] == [256, 256, 256, 232]
+    assert all(kind == "idx" and whole is base for kind, _, whole in b)
+    assert torch.equal(torch.cat([v for _, v, _ in b]), base) and torch.equal(b[-1][1], base[768:])
+    assert [x[1].numel() for x in b[3:]] == [232] and b[4:] == []
+    r = _Batches("range", 7, 513, 256)
+    assert list(r) == [("range", 7, 256), ("range", 263, 256), ("range", 519, 1)] and r.full() == 2
+    assert len(_Batches("range", 0, 0, 32)) == 0 and _Batches("range", 0, 5, 32).full() == 0
+    with pytest.raises(IndexError):
+        r[3]
+    rng = np.random.default_rng(3)
+    for d in (1, 2, 4):
+        A = rng.standard_normal((9, d, 3 * d))
+        C0 = A @ np.swapaxes(A, -1, -2) / (3 * d)
+        B = rng.standard_normal((9, d, d))
+        Ct = 0.3 * (B + np.swapaxes(B, -1, -2))
+        ev, V = linalg.tica_eigh_stack(C0, Ct, 1e-6)
+        for i in range(9):
+            e1, v1 = linalg.tica_eigh(C0[i], Ct[i], 1e-6)
+            assert np.array_equal(e1, ev[i]) and np.array_equal(v1, V[i])
+    assert linalg.tica_eigh_stack(np.zeros((0, 2, 2)), np.zeros((0, 2, 2)))[0].shape == (0, 2)
+    before = torch.get_num_threads()
+    torch.manual_seed(11)
+    a = torch.randperm(50000)
+    torch.manual_seed(11)
+    with _torch_threads(1):
+        assert torch.get_num_threads() == 1
+        c = torch.randperm(50000)
+    assert torch.get_num_threads() == before and torch.equal(a, c)

@@ -933,12 +933,7 @@ class NonLinear(CVCalculator):
                 return _Batches("range", off, n, batch_size if batch_size > 0 else n)
         idx = part
         if self.shuffle:
-            # the reference's permutation (global CPU generator); torch.randperm is a sequential algorithm whose result does not
-            # depend on the intra-op thread count, but with the 128 threads of a GPU host it takes 15 ms for 160 000 indices
-            # against 1.3 ms with 8 (thread start-up for its fill / copy loops)
-            with _torch_threads(8):
-                perm = torch.randperm(len(idx))
-            idx = idx[perm]
+            idx = idx[torch.randperm(len(idx))]   # the reference's permutation (global CPU generator)
         bs = batch_size if batch_size > 0 else len(idx)
         idx_d = idx.to(dev).contiguous()   # one copy per epoch; the batches are consecutive views of it (third field: the whole list)
         return _Batches("idx", idx_d, len(idx), bs)
@@ -1018,7 +1013,12 @@ class NonLinear(CVCalculator):
         for try_num in range(1, self.num_tries + 1):
             self.tries = try_num
             try:
-                result = self._train_once(try_num, dims, acts, drops, latent, opt_name, opt_kw, n_local, n_val_local, local_bs, dev)
+                # The host side of a try is small torch-CPU work (a randperm and a gather per epoch, the initialisation of a few
+                # Linears): with the 128 intra-op threads of a GPU host torch.randperm takes 15 ms for 160 000 indices against
+                # 1.3 ms with 8 (its result does not depend on the count: tests/test_host_cpu.py).  Capped once per try --
+                # growing the pool back costs ~12 ms, so not per epoch.
+                with _torch_threads(8):
+                    result = self._train_once(try_num, dims, acts, drops, latent, opt_name, opt_kw, n_local, n_val_local, local_bs, dev)
             except Exception as e:
                 logger.error(f"Training try {try_num} failed with an exception: {e}")
                 continue

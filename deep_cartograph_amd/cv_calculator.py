@@ -1095,13 +1095,20 @@ class NonLinear(CVCalculator):
         best_score, best_state, last_state = float("inf"), None, None
         es_best, wait = float("inf"), 0
         last_valid = None
+        next_tb = None
         for epoch in range(self.max_epochs):
-            tb = self._batches(train_part, bs, dev)
+            tb = next_tb if next_tb is not None else self._batches(train_part, bs, dev)
             do_val = (epoch + 1) % self.check_val_every_n_epoch == 0
             vb = self._batches(val_part, bs, dev) if do_val else []
             self.engine.reset_log(len(tb) + len(vb))
             self._run_batches(Xn_train, tb, True, gb, per_step=sched.after_step if sched is not None else None)
             self._run_batches(Xn_val, vb, False, gb)
+            # While the device works through the epoch just enqueued: the NEXT epoch's permutation and index upload (a CPU
+            # randperm of 10 M indices is ~0.1 s -- as long as the epoch itself).  The draws keep the reference's order (train
+            # loader, validation loader, next train loader ...); if this epoch turns out to be the last one, the generator is put
+            # back where the reference's would be.
+            rng_before_prefetch = torch.get_rng_state() if self.shuffle else None
+            next_tb = self._batches(train_part, bs, dev) if self.shuffle and epoch + 1 < self.max_epochs else None
             rec = self.engine.read_log()   # the only host sync of the epoch
             if not np.all(np.isfinite(rec[:, 0])):
                 raise FloatingPointError("non-finite loss (ill-conditioned batch covariance?)")
@@ -1132,6 +1139,8 @@ class NonLinear(CVCalculator):
             if sched is not None:
                 sched.after_epoch(last_valid)
             if stop:
+                if next_tb is not None:
+                    torch.set_rng_state(rng_before_prefetch)
                 break
         if metrics["valid_loss"] and min(metrics["valid_loss"]) > metrics["valid_loss"][0]:
             logger.warning(f"Try {try_num}: validation loss did not decrease during training.")

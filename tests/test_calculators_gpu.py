@@ -520,3 +520,42 @@ def test_clustering_scores_match_sklearn(golden_proj):
     np.testing.assert_allclose(si, silhouette_score(P, lab), rtol=1e-9)
     np.testing.assert_allclose(ch, calinski_harabasz_score(P, lab), rtol=1e-9)
     np.testing.assert_allclose(db, davies_bouldin_score(P, lab), rtol=1e-9)
+
+
+@pytest.mark.parametrize("kind", ["deep_tica", "ae"])
+def test_shuffled_loader_fit_follows_the_oracle_and_its_rng_stream(kind, tmp_path):
+    """The reference's DEFAULT loader (shuffle + random split) through the calculators' epoch loop as it runs now -- the
+    training steps of an epoch behind one dcv_mlp_train_steps call, the validation pass behind dcv_mlp_eval_steps, the next
+    epoch's permutation drawn while the device works -- against the oracle's step-by-step loop: same epochs (early stopping
+    ends both runs early), same validation losses, and the global generator left exactly where the oracle's run leaves it
+    (the permutation prefetched for an epoch that never ran is given back)."""
+    from tests.test_mlp_gpu import ar_features
+
+    X = ar_features(6000, 64, 29)
+    lag, dim, bs = 4, 2, 256
+    training = json.loads(json.dumps(TEST_COMMON["training"]))
+    training["general"].update({"batch_size": bs, "max_epochs": 30, "seed": 11, "shuffle": True, "random_split": True})
+    training["early_stopping"].update({"patience": 2, "min_delta": 0.05})   # stops after a few epochs
+    calc = make_calc(kind, tmp_path, dimension=dim, lag_time=lag, architecture=WELL_ARCH, training=training)
+    calc.set_training_matrix(X.copy())
+    assert calc.train()
+    after_calc = torch.rand(4)
+    m, r = calc.features_norm_mean.astype(np.float32), calc.features_norm_range.astype(np.float32)
+    kw = dict(seed_try=12, lengths=[0.8, 0.2], batch_size=bs, shuffle=True, random_split=True, max_epochs=30,
+              check_val_every_n_epoch=1, save_check_every_n_epoch=1, patience=2, min_delta=0.05,
+              opt_kwargs={"lr": 1e-3, "weight_decay": 0}, model_to_save="last")
+    Xt = torch.from_numpy(X)
+    md, rd = torch.from_numpy(m), torch.from_numpy(r)
+    if kind == "deep_tica":
+        build = lambda: onn.DeepTICAModel([64, 32, 16, dim], ["tanh", "tanh", None], [0.0, 0.0, None], md, rd, 1e-6)
+        res = onn.train(None, {"data": Xt[:-lag], "data_lag": Xt[lag:]}, build_model=build, **kw)
+    else:
+        build = lambda: onn.AEModel([64, 32, 16, dim], ["tanh", "tanh", None], [0.0, 0.0, None], [dim, 16, 32, 64], ["tanh", "tanh", None],
+                                    [0.0, 0.0, None], md, rd)
+        res = onn.train(None, {"data": Xt}, build_model=build, **kw)
+    after_oracle = torch.rand(4)
+    n_ep = len(res["metrics"]["epoch"])
+    assert 3 <= n_ep < 30 and len(calc.metrics["epoch"]) == n_ep
+    np.testing.assert_allclose(calc.metrics["valid_loss"], res["metrics"]["valid_loss"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(calc.metrics["train_loss"], res["metrics"]["train_loss"], rtol=2e-4, atol=2e-6)
+    assert torch.equal(after_calc, after_oracle)

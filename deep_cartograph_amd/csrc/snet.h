@@ -29,82 +29,36 @@ struct SnetLayer {
 // Arithmetic = reduce_quad_block<4> of mlp.hip bit for bit: partial q is added, in float64, to accumulator q mod 4 in
 // increasing q, the four are combined in order 0..3, rounded once.
 constexpr int kSnetReduceMaxWg = 32;   // (above 32 partials the reduction kernel walks them in 16 groups: a different sum order)
-constexpr int64_t kSnetReduceMaxLoads = 64 * 1024;   // parameters x workgroups one workgroup is asked to add up (the reference's networks: 1.2 - 1.4 K parameters)
-// every thread of the LAST workgroup, after handoff_arrive_last (the partials were stored write-through).  One flat element
-// space over all layers' weights and biases, four elements per thread in flight with eight partials each: the whole reduction
-// is two or three memory round trips (a loop over the items -- six for a three-layer network -- paid a full round trip per
-// item and made the step 7 us LONGER than with the separate launch).
+// every thread of the LAST workgroup, after handoff_arrive_last (the partials were stored write-through)
 template <int NT>
 __device__ __forceinline__ void snet_reduce_update(const SnetLayer* l, int L, const float* part, int nwg, const SnetReduce& r, int t) {
-    constexpr int EU = 4;
-    int total = 0;
-    for (int li = 0; li < L; ++li) total += l[li].out * l[li].in + l[li].out;
-    for (int base = 0; base < total; base += EU * NT) {
-        // element -> (offset of its partial 0 in `part`, stride between partials, parameter index).  An element past the end
-        // keeps offset 0 / stride 0 / parameter 0: its loads stay UNCONDITIONAL (a load inside a branch gets a full
-        // s_waitcnt vmcnt(0) behind it from hipcc -- 32 dependent round trips instead of four loads in flight) and valid,
-        // its sums are never finished.
-        int64_t off[EU], stride[EU], dst[EU];
-        bool ok[EU];
+    for (int li = 0; li < 2 * L; ++li) {
+        const SnetLayer& y = l[li >> 1];
+        const bool bias = li & 1;
+        const int count = bias ? y.out : y.out * y.in;
+        const int64_t dst = bias ? y.b_off : y.w_off;
+        const float* src = part + (bias ? y.pb_off : y.pw_off);
+        const int64_t stride = bias ? y.pb_stride : y.pw_stride;
+        for (int e = t; e < count; e += NT) {
+            const float pi = handoff_load(r.params + dst + e);   // (sc1 like every load behind the ticket; no workgroup writes it in this launch)
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            const float* p = src + e;
+            int q = 0;
+            for (; q + 8 <= nwg; q += 8) {   // eight loads in flight
+                float v[8];
 #pragma unroll
-        for (int u = 0; u < EU; ++u) {
-            int idx = base + u * NT + t;
-            ok[u] = idx < total;
-            off[u] = 0;
-            stride[u] = 0;
-            dst[u] = 0;
-            bool found = !ok[u];
-            for (int li = 0; li < L; ++li) {
-                const SnetLayer& y = l[li];
-                const int cw = y.out * y.in;
-                const bool in_w = !found && idx < cw;
-                off[u] = in_w ? y.pw_off + idx : off[u];
-                stride[u] = in_w ? (int64_t)y.pw_stride : stride[u];
-                dst[u] = in_w ? y.w_off + idx : dst[u];
-                found = found || in_w;
-                idx = found ? idx : idx - cw;
-                const bool in_b = !found && idx < y.out;
-                off[u] = in_b ? y.pb_off + idx : off[u];
-                stride[u] = in_b ? (int64_t)y.pb_stride : stride[u];
-                dst[u] = in_b ? y.b_off + idx : dst[u];
-                found = found || in_b;
-                idx = found ? idx : idx - y.out;
+                for (int u = 0; u < 8; ++u) v[u] = handoff_load(p + (int64_t)(q + u) * stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[u & 3] += (double)v[u];
             }
-        }
-        float pi[EU];
-        double acc[EU][4];
-#pragma unroll
-        for (int u = 0; u < EU; ++u) {
-            pi[u] = handoff_load(r.params + dst[u]);   // (sc1 like every load behind the ticket; no workgroup writes it in this launch)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[u][c] = 0.0;
-        }
-        for (int q = 0; q < nwg; q += 8) {
-            float v[EU][8];
-#pragma unroll
-            for (int u = 0; u < EU; ++u)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int qq = q + j < nwg ? q + j : nwg - 1;   // (uniform; a clamped partial is loaded and not added)
-                    v[u][j] = handoff_load(part + off[u] + (int64_t)qq * stride[u]);
-                }
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-                if (q + j < nwg) {   // partial q + j into accumulator (q + j) mod 4, increasing order
-#pragma unroll
-                    for (int u = 0; u < EU; ++u) acc[u][j & 3] += (double)v[u][j];
-                }
-        }
-#pragma unroll
-        for (int u = 0; u < EU; ++u) {
-            if (!ok[u]) continue;
-            double tot = acc[u][0];
-            tot += acc[u][1];
-            tot += acc[u][2];
-            tot += acc[u][3];
+            for (; q < nwg; ++q) acc[q & 3] += (double)handoff_load(p + (int64_t)q * stride);
+            double tot = acc[0];
+            tot += acc[1];
+            tot += acc[2];
+            tot += acc[3];
             const float gr = (float)(tot * (double)1.f);
-            handoff_store(r.grads + dst[u], gr);
-            opt_update_p<true>(dst[u], gr, pi[u], r.params, r.s1, r.s2, r.s3, r.oa);
+            handoff_store(r.grads + dst + e, gr);
+            opt_update_p<true>(dst + e, gr, pi, r.params, r.s1, r.s2, r.s3, r.oa);
         }
     }
 }

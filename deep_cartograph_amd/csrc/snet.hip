@@ -603,7 +603,7 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     static const bool red_off = [] { const char* e = getenv("DCV_SNET_INLINE_REDUCE"); return e && e[0] == '0'; }();
     a.red = SnetReduce{};
     if (reduced) *reduced = false;
-    if (red != nullptr && train && nb == 1 && nwg <= kSnetReduceMaxWg && nwg * m->n_params <= kSnetReduceMaxLoads && !red_off) {
+    if (red != nullptr && train && nb == 1 && nwg <= kSnetReduceMaxWg && !red_off) {
         a.red = *red;
         a.red.on = 1;
         if (reduced) *reduced = true;

@@ -832,7 +832,7 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head,
     a.red = SnetReduce{};
     a.rticket = m->ticket + 1;
     if (reduced) *reduced = false;
-    if (red != nullptr && nwg <= kSnetReduceMaxWg && nwg * m->n_params <= kSnetReduceMaxLoads && !red_off) {
+    if (red != nullptr && nwg <= kSnetReduceMaxWg && !red_off) {
         a.red = *red;
         a.red.on = 1;
         if (reduced) *reduced = true;

@@ -112,12 +112,10 @@ struct ReduceArgsView {
 // lands in a timed validation pass)
 constexpr int kEvalBatchesPerLaunch = 64;
 constexpr int64_t kEvalWorkgroupsPerLaunch = 4096;
-struct SnetReduce;   // snet.h: the in-launch gradient reduction + optimiser update of small grids
 // snet.hip: the whole autoencoder step in one launch when the network fits in LDS; 1 = not applicable
 // R rows of this rank, `batch` = the GLOBAL batch (loss scale 2 / (batch * F)); write_log = false: the caller logs (after an all-reduce)
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
-                 hipStream_t s, bool write_log = true, int nb = 1,   // nb > 1: that many evaluation batches of R rows in one launch
-                 const SnetReduce* red = nullptr, bool* reduced = nullptr);   // small grids reduce + update in the launch (snet.h)
+                 hipStream_t s, bool write_log = true, int nb = 1);   // nb > 1: that many evaluation batches of R rows in one launch
 int snet_ae_tile_rows(dcv_mlp* m);   // rows per workgroup of the fused step (builds the plan on first use); 0: not applicable
 void snet_free(dcv_mlp* m);
 // the weight image both fused small-network plans stage from (snet.hip); repack: after the parameters were written by anyone
@@ -129,8 +127,7 @@ void snet_image_free(dcv_mlp* m);
 // nb > 1 (head == 2, no blob): that many evaluation batches of `batch` pairs in one launch, batch j = the pairs [j * batch, (j + 1) * batch)
 int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* idx_d, int64_t row0, int32_t batch, int head, bool keep_blob,
                     hipStream_t s, int nb = 1);
-int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s,
-                     const SnetReduce* red = nullptr, bool* reduced = nullptr);
+int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s);
 void snet_dt_free(dcv_mlp* m);
 // bn.hip
 int bn_forward(dcv_mlp* m, int l, int64_t row0, int64_t rows, bool train, hipStream_t s);

@@ -4,7 +4,6 @@
 #pragma once
 #include <hip/hip_ext.h>
 #include "mlp_state.h"
-#include "opt.h"
 #include <vector>
 
 namespace dcv {
@@ -23,46 +22,6 @@ struct SnetLayer {
     int64_t pw_off, pb_off;     // gradient partials: part + pw_off + wg * pw_stride ; part + pb_off + wg * pb_stride
     int pw_stride, pb_stride;   // out * in and out rounded up to multiples of 4 floats (16-byte loads in the reduction)
 };
-// In-launch gradient reduction + optimiser update of a SMALL grid (<= kSnetReduceMaxWg workgroups; the reference's own batch
-// sizes are 4 - 16 workgroups): the ticketed last arriver of the launch adds the workgroups' partials and updates the
-// parameters itself -- the separate reduce_grads_quad_kernel launch (4.6 - 5.3 us + a kernel boundary of a 29 us step) goes.
-// Arithmetic = reduce_quad_block<4> of mlp.hip bit for bit: partial q is added, in float64, to accumulator q mod 4 in
-// increasing q, the four are combined in order 0..3, rounded once.
-constexpr int kSnetReduceMaxWg = 32;   // (above 32 partials the reduction kernel walks them in 16 groups: a different sum order)
-// every thread of the LAST workgroup, after handoff_arrive_last (the partials were stored write-through)
-template <int NT>
-__device__ __forceinline__ void snet_reduce_update(const SnetLayer* l, int L, const float* part, int nwg, const SnetReduce& r, int t) {
-    for (int li = 0; li < 2 * L; ++li) {
-        const SnetLayer& y = l[li >> 1];
-        const bool bias = li & 1;
-        const int count = bias ? y.out : y.out * y.in;
-        const int64_t dst = bias ? y.b_off : y.w_off;
-        const float* src = part + (bias ? y.pb_off : y.pw_off);
-        const int64_t stride = bias ? y.pb_stride : y.pw_stride;
-        for (int e = t; e < count; e += NT) {
-            const float pi = handoff_load(r.params + dst + e);   // (sc1 like every load behind the ticket; no workgroup writes it in this launch)
-            double acc[4] = {0.0, 0.0, 0.0, 0.0};
-            const float* p = src + e;
-            int q = 0;
-            for (; q + 8 <= nwg; q += 8) {   // eight loads in flight
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = handoff_load(p + (int64_t)(q + u) * stride);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc[u & 3] += (double)v[u];
-            }
-            for (; q < nwg; ++q) acc[q & 3] += (double)handoff_load(p + (int64_t)q * stride);
-            double tot = acc[0];
-            tot += acc[1];
-            tot += acc[2];
-            tot += acc[3];
-            const float gr = (float)(tot * (double)1.f);
-            handoff_store(r.grads + dst + e, gr);
-            opt_update_p<true>(dst + e, gr, pi, r.params, r.s1, r.s2, r.s3, r.oa);
-        }
-    }
-}
-
 __device__ __forceinline__ sv4f mfma4(float a, float b, sv4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // Contraction lengths are compile-time (NK chunks of 16; the plan pads every width to 16 * 2^j): the fragment reads of

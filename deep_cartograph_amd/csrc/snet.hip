@@ -49,7 +49,6 @@ struct SnetArgs {
     int* log_count;
     int log_cap, log_width;
     unsigned long long* stamps;   // diagnostic (dcv_debug_snet_stamps): s_memrealtime of workgroup 0 at the phase boundaries, or null
-    SnetReduce red;               // small grids: the last arriver reduces the gradient partials and applies the optimiser update
 };
 #define SNET_STAMP(k)                                                                          \
     do {                                                                                        \
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                         } else {
 #pragma unroll
                             for (int v = 0; v < 4; ++v)
-                                if (i0 + v < y.in) handoff_store(dst + v, acc[v]);
+                                if (i0 + v < y.in) dst[v] = acc[v];
                         }
                     }
                     it += kSnetWaves;
@@ -299,7 +298,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
                     for (int r = 0; r < TR / 4; ++r) s += dZ[(part * (TR / 4) + r) * psz + o];
                     s += __shfl_xor(s, 1, 64);
                     s += __shfl_xor(s, 2, 64);
-                    if (part == 0 && o < y.out) handoff_store(a.part + y.pb_off + (int64_t)blockIdx.x * y.pb_stride + o, s);   // (write-through: the last arriver may reduce them in this launch)
+                    if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.pb_stride + o] = s;
                 }
             }
             SNET_STAMP(21 + 2 * l);
@@ -359,9 +358,6 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
             }
         }
     }
-    // ---- small grids: gradient reduction + optimiser update by this (the last) workgroup -- every other workgroup has
-    //      arrived, i.e. has long finished reading the parameters and has its partials stored write-through
-    if (a.train && a.red.on) snet_reduce_update<NT>(a.l, a.L, a.part, (int)gridDim.x, a.red, t);
 }
 
 struct SnetPlan {
@@ -539,11 +535,8 @@ int snet_ae_tile_rows(dcv_mlp* m) {
 // path), DCV_OK when the launch was enqueued.
 // nb > 1 (evaluation only): nb batches of R rows each in the one launch -- batch j = the logical rows [j * R, (j + 1) * R) of
 // `rm` -- with one loss record per batch, appended in batch order.
-// red != null (one-GPU training step, the optimiser arguments of this step): grids of <= kSnetReduceMaxWg workgroups reduce their
-// partials and update the parameters inside the launch; *reduced says whether that happened (else the caller launches the
-// reduction).
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
-                 hipStream_t s, bool write_log, int nb, const SnetReduce* red, bool* reduced) {
+                 hipStream_t s, bool write_log, int nb) {
     static const int64_t kMaxPartBytes = 96ll << 20;
     if (snet_ae_tile_rows(m) == 0) return 1;
     SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
@@ -600,14 +593,6 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     a.log_cap = m->log_cap;
     a.log_width = m->log_width;
     a.stamps = pl->stamps;
-    static const bool red_off = [] { const char* e = getenv("DCV_SNET_INLINE_REDUCE"); return e && e[0] == '0'; }();
-    a.red = SnetReduce{};
-    if (reduced) *reduced = false;
-    if (red != nullptr && train && nb == 1 && nwg <= kSnetReduceMaxWg && !red_off) {
-        a.red = *red;
-        a.red.on = 1;
-        if (reduced) *reduced = true;
-    }
     auto launch = [&](auto kern) -> int {
         static int attr_state[2] = {0, 0};   // 0 unknown, 1 set, -1 refused by the runtime (the fused form is then off)
         const int slot = pl->TR == 32 ? 0 : 1;

@@ -55,8 +55,6 @@ struct SnetDtArgs {
     FusedHead fused;
     const double* gradp;          // backward: [mu d | Gu d*d | Gv d*d | c d]
     float* part;                  // backward: gradient partials
-    SnetReduce red;               // backward, small grids: the last arriver reduces the partials and applies the optimiser update
-    unsigned* rticket;            //   its ticket (zero between launches)
 };
 
 template <int NARGS>
@@ -534,7 +532,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
                     } else {
 #pragma unroll
                         for (int v = 0; v < 4; ++v)
-                            if (i0 + v < y.in) handoff_store(dst + v, acc[v]);
+                            if (i0 + v < y.in) dst[v] = acc[v];
                     }
                 }
                 it += kSnetWaves;
@@ -547,7 +545,7 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
                 for (int r = 0; r < TR / 4; ++r) s += dZ[(part * (TR / 4) + r) * psz + o];
                 s += __shfl_xor(s, 1, 64);
                 s += __shfl_xor(s, 2, 64);
-                if (part == 0 && o < y.out) handoff_store(a.part + y.pb_off + (int64_t)blockIdx.x * y.pb_stride + o, s);   // (write-through: see the tail)
+                if (part == 0 && o < y.out) a.part[y.pb_off + (int64_t)blockIdx.x * y.pb_stride + o] = s;
             }
         }
         if (l == 0) break;
@@ -568,12 +566,6 @@ __global__ __launch_bounds__(kSnetThreads) void snet_dt_bwd_kernel(SnetDtArgs a)
             }
         }
         __syncthreads();
-    }
-    // ---- small grids: the last workgroup to arrive adds the partials and applies the optimiser update (snet.h) -- every other
-    //      workgroup has staged its weights long ago and has its partials stored write-through
-    if (a.red.on) {
-        __shared__ unsigned s_last;
-        if (handoff_arrive_last(a.rticket, gridDim.x, &s_last)) snet_reduce_update<NT>(a.l, a.L, a.part, (int)gridDim.x, a.red, t);
     }
 }
 
@@ -782,10 +774,7 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
 // Fused backward of the batch whose forward snet_dt_forward ran last (its blob is in place): gradient partials for the
 // reduction, whose descriptors go to `ra`.  head: the loss head has not run yet -- every workgroup evaluates it from m->stats
 // (the sums over the GLOBAL batch) and the first one appends the loss record; otherwise m->gradp holds the head's matrices.
-// red != null (one-GPU training step): grids of <= kSnetReduceMaxWg workgroups reduce their partials and update the parameters
-// inside the launch; *reduced says whether that happened.
-int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s, const SnetReduce* red,
-                     bool* reduced) {
+int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head, ReduceArgsView* ra, hipStream_t s) {
     SnetDtPlan* pl = static_cast<SnetDtPlan*>(m->snet_dt);
     if (!pl || !pl->blob) {
         set_error("snet_dt_backward: no fused forward to go back through");
@@ -828,15 +817,6 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head,
     a.stats = m->stats;
     a.fused = FusedHead{0, 0.0, 0.0, nullptr, nullptr, nullptr, 0, 0};
     if (head) a.fused = FusedHead{1, (double)global_batch, m->desc.tica_reg, nullptr, m->log, m->log_count, m->log_cap, m->log_width};
-    static const bool red_off = [] { const char* e = getenv("DCV_SNET_INLINE_REDUCE"); return e && e[0] == '0'; }();
-    a.red = SnetReduce{};
-    a.rticket = m->ticket + 1;
-    if (reduced) *reduced = false;
-    if (red != nullptr && nwg <= kSnetReduceMaxWg && !red_off) {
-        a.red = *red;
-        a.red.on = 1;
-        if (reduced) *reduced = true;
-    }
     switch (TR) {
         case 32: return snet_dt_launch(snet_dt_bwd_kernel<32>, 4, lds_bytes, a, nwg, s);
         case 64: return snet_dt_launch(snet_dt_bwd_kernel<64>, 5, lds_bytes, a, nwg, s);

@@ -106,31 +106,24 @@ __device__ __forceinline__ void opt_st(float* p, float v) {
     if constexpr (WT) handoff_store(p, v);
     else *p = v;
 }
-// What a caller already holds of element i when it calls opt_update_p (the fused reduction kernel requests these with the
-// parameter itself, ahead of the partial sums: loaded on demand they were two more dependent memory round trips at the tail of
-// every training step -- the Adam moments behind the reduction, the image index behind the update)
-struct OptPre {
-    float s1, s2;   // Adam / AdamW: exp_avg[i], exp_avg_sq[i]
-    int img;        // a.img_idx[i] (-1: not in the image, or no image)
-};
 template <bool WT>
-__device__ __forceinline__ void opt_stp(const OptArgs& a, const OptPre* pre, float* p, int64_t i, float v) {
+__device__ __forceinline__ void opt_stp(const OptArgs& a, float* p, int64_t i, float v) {
     opt_st<WT>(p + i, v);
     if (a.img != nullptr) {
-        const int j = pre != nullptr ? pre->img : a.img_idx[i];
+        const int j = a.img_idx[i];
         if (j >= 0) opt_st<WT>(a.img + j, v);
     }
 }
 template <bool WT = false>
 __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, float* __restrict__ p, float* __restrict__ s1, float* __restrict__ s2,
-                                             float* __restrict__ s3, const OptArgs& a, const OptPre* pre = nullptr) {
+                                             float* __restrict__ s3, const OptArgs& a) {
     if (a.maximize) gi = -gi;   // `grad = grads[i] if not maximize else -grads[i]`: the first line of every _single_tensor_* update
     switch (a.kind) {
         case DCV_OPT_ADAM:
         case DCV_OPT_ADAMW: {
             if (a.kind == DCV_OPT_ADAMW) pi = pi * a.decay;                        // param.mul_(1 - lr * weight_decay)
             else if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);                        // grad.add(param, alpha=weight_decay)
-            float mi = pre != nullptr ? pre->s1 : s1[i], vi = pre != nullptr ? pre->s2 : s2[i];
+            float mi = s1[i], vi = s2[i];
             mi = mi + (gi - mi) * a.w1;                                           // exp_avg.lerp_(grad, 1 - beta1)
             vi = vi * a.b2 + a.w2 * gi * gi;                                      // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
             float vden = vi;
@@ -141,7 +134,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float denom = sqrtf(vden) / a.c2 + a.eps;
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, vi);
-            opt_stp<WT>(a, pre, p, i, pi - a.c1 * (mi / denom));                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
+            opt_stp<WT>(a, p, i, pi - a.c1 * (mi / denom));                                      // param.addcdiv_(exp_avg, denom, value=-step_size)
             break;
         }
         case DCV_OPT_SGD: {
@@ -151,7 +144,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
                 opt_st<WT>(s1 + i, bi);
                 gi = a.flag ? fmaf(a.b1, bi, gi) : bi;                            // nesterov: grad.add(buf, alpha=momentum)
             }
-            opt_stp<WT>(a, pre, p, i, pi - a.lr * gi);
+            opt_stp<WT>(a, p, i, pi - a.lr * gi);
             break;
         }
         case DCV_OPT_RMSPROP: {
@@ -170,9 +163,9 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             if (a.b1 > 0.f) {                                                      // b1 = momentum
                 const float bi = s1[i] * a.b1 + gi / avg;                          // buf.mul_(momentum).addcdiv_(grad, avg)
                 opt_st<WT>(s1 + i, bi);
-                opt_stp<WT>(a, pre, p, i, pi - a.lr * bi);
+                opt_stp<WT>(a, p, i, pi - a.lr * bi);
             } else {
-                opt_stp<WT>(a, pre, p, i, pi - a.lr * (gi / avg));
+                opt_stp<WT>(a, p, i, pi - a.lr * (gi / avg));
             }
             break;
         }
@@ -183,7 +176,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float ui = fmaxf(s2[i] * a.b2, fabsf(gi) + a.eps);              // maximum(exp_inf * beta2, |grad| + eps)
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, ui);
-            opt_stp<WT>(a, pre, p, i, pi - a.c1 * (mi / ui));                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
+            opt_stp<WT>(a, p, i, pi - a.c1 * (mi / ui));                                         // addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction)
             break;
         }
         case DCV_OPT_NADAM: {    // _single_tensor_nadam: p0 = -lr (1 - mu) / (1 - mu_product), p1 = -lr mu_next / (1 - mu_product_next), c2 = 1 - beta2^t
@@ -198,7 +191,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, vi);
             pi = pi + a.p0 * (gi / denom);
-            opt_stp<WT>(a, pre, p, i, pi + a.p1 * (mi / denom));
+            opt_stp<WT>(a, p, i, pi + a.p1 * (mi / denom));
             break;
         }
         case DCV_OPT_RADAM: {    // _single_tensor_radam: c1 = 1 - beta1^t, c2 = sqrt(1 - beta2^t), p0 = rect (0: rho_t <= 5)
@@ -212,8 +205,8 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             opt_st<WT>(s1 + i, mi);
             opt_st<WT>(s2 + i, vi);
             const float mhat = mi / a.c1;
-            if (a.p0 > 0.f) opt_stp<WT>(a, pre, p, i, pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0);
-            else opt_stp<WT>(a, pre, p, i, pi - mhat * a.lr);
+            if (a.p0 > 0.f) opt_stp<WT>(a, p, i, pi - ((mhat * a.lr) * (a.c2 / (sqrtf(vi) + a.eps))) * a.p0);
+            else opt_stp<WT>(a, p, i, pi - mhat * a.lr);
             break;
         }
         case DCV_OPT_ADADELTA: { // _single_tensor_adadelta: s1 = square_avg, s2 = acc_delta, b2 = rho, w2 = 1 - rho
@@ -223,13 +216,13 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             const float delta = sqrtf(acc + a.eps) / sqrtf(sq + a.eps) * gi;
             opt_st<WT>(s1 + i, sq);
             opt_st<WT>(s2 + i, acc * a.b2 + a.w2 * delta * delta);
-            opt_stp<WT>(a, pre, p, i, pi - a.lr * delta);
+            opt_stp<WT>(a, p, i, pi - a.lr * delta);
             break;
         }
         case DCV_OPT_ASGD: {     // _single_tensor_asgd: p0 = 1 - lambd * eta, p1 = eta (the averaged copy ax is not kept)
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             pi = pi * a.p0;
-            opt_stp<WT>(a, pre, p, i, pi - a.p1 * gi);
+            opt_stp<WT>(a, p, i, pi - a.p1 * gi);
             break;
         }
         case DCV_OPT_RPROP: {    // _single_tensor_rprop: s1 = prev, s2 = step_size; p0 / p1 = eta minus / plus, p2 / p3 = step bounds
@@ -239,7 +232,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             opt_st<WT>(s2 + i, st);
             if (sg < 0.f) gi = 0.f;
             const float sgn = gi > 0.f ? 1.f : (gi < 0.f ? -1.f : 0.f);
-            opt_stp<WT>(a, pre, p, i, pi - sgn * st);
+            opt_stp<WT>(a, p, i, pi - sgn * st);
             opt_st<WT>(s1 + i, gi);
             break;
         }
@@ -247,7 +240,7 @@ __device__ __forceinline__ void opt_update_p(int64_t i, float gi, float pi, floa
             if (a.wd != 0.f) gi = fmaf(a.wd, pi, gi);
             const float su = s2[i] + gi * gi;                                      // state_sum.addcmul_(grad, grad, value=1)
             opt_st<WT>(s2 + i, su);
-            opt_stp<WT>(a, pre, p, i, pi - a.c1 * (gi / (sqrtf(su) + a.eps)));                         // param.addcdiv_(grad, std, value=-clr)
+            opt_stp<WT>(a, p, i, pi - a.c1 * (gi / (sqrtf(su) + a.eps)));                         // param.addcdiv_(grad, std, value=-clr)
             break;
         }
     }
@@ -371,15 +364,7 @@ __device__ __forceinline__ void reduce_quad_block(const QuadItem& d, int blk, fl
     const int mine = base + t;
     const bool fin = t < EPB && mine < d.count;
     float pi = 0.f;
-    OptPre pre{0.f, 0.f, -1};
-    if (fuse && fin) {   // everything the update needs of its element, requested ahead of the partials
-        pi = params[d.dst + mine];
-        if (oa.kind == DCV_OPT_ADAM || oa.kind == DCV_OPT_ADAMW) {
-            pre.s1 = s1[d.dst + mine];
-            pre.s2 = s2[d.dst + mine];
-        }
-        if (oa.img != nullptr) pre.img = oa.img_idx[d.dst + mine];
-    }
+    if (fuse && fin) pi = params[d.dst + mine];
     const int e0 = base + 4 * sub;
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     if (e0 < d.count && (d.stride & 3) == 0 && e0 + 4 <= d.stride && (reinterpret_cast<uintptr_t>(d.src) & 15) == 0) {
@@ -412,7 +397,7 @@ __device__ __forceinline__ void reduce_quad_block(const QuadItem& d, int blk, fl
         for (int k = 1; k < G; ++k) tot += s_red[k * EPB + t];
         const float gr = (float)(tot * (double)scale);
         handoff_store(grads + d.dst + mine, gr);
-        if (fuse) opt_update_p<true>(d.dst + mine, gr, pi, params, s1, s2, s3, oa, &pre);
+        if (fuse) opt_update_p<true>(d.dst + mine, gr, pi, params, s1, s2, s3, oa);
     }
 }
 __global__ __launch_bounds__(256) void reduce_grads_quad_kernel(QuadArgs a, float* __restrict__ grads, float scale, int fuse,

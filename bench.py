@@ -71,6 +71,10 @@ def parse():
     p.add_argument("--ref-small-steps", type=int, default=300,
                    help="one GPU only: append block 'ref_small' -- Deep-TICA on the reference's own network sizes (54-16-8-2 of its test "
                         "configuration, [15, 15] of default_config.yml) at batch 128 and 4096; 0 disables")
+    p.add_argument("--fit-epochs", type=int, default=10,
+                   help="one GPU only: append block 'calculator_fit' -- wall clock of CVCalculator.train() (the WHOLE host path of a fit: split, "
+                        "initialisation, per-epoch permutation, steps, validation, log read-back, metrics, checkpoints) for Deep-TICA and the "
+                        "autoencoder on 200 000 x 54 features with the reference's default architecture and loader; 0 disables")
     p.add_argument("--config", choices=["c4", "c2", "ref_small"], default="c4",
                    help="c4 (default): the headline, Deep-TICA on 10M x 512; c2: BASELINE.json configs[1], autoencoder 128-64-32-2-32-64-128 on "
                         "1M x 128 at batch 4096 (its own metric line with roofline and cpu_baseline; one GPU)")
@@ -490,6 +494,47 @@ def run_c2(a, steps, warmup, cpu_seconds):
     return out
 
 
+def run_calculator_fit(epochs):
+    """The calculators themselves, end to end: `train()` of the Deep-TICA and autoencoder calculators (the reference's
+    NonLinear.train, cv_calculator.py:1456-1553) on 200 000 x 54 synthetic features with the reference's default architecture
+    ([16, 8] encoder), lag 5, its default loader (random split + shuffle), Adam 1e-3, `epochs` epochs with a validation pass each,
+    at the batch sizes 256 and 4096.  Wall clock around the call: everything the host does per epoch is inside."""
+    import contextlib
+    import tempfile
+
+    from deep_cartograph_amd.cv_calculator import cv_calculators_map
+    from deep_cartograph_amd.synth import synth_features
+
+    n, F = 200_000, 54
+    X = synth_features(n, F, k_slow=2, shard=0, device="cuda").cpu().numpy()
+    names = [f"f{i}" for i in range(F)]
+    arch = {"encoder": {"layers": [16, 8], "activation": ["leaky_relu", "leaky_relu"], "batchnorm": [False, False], "dropout": [0, 0],
+                        "last_layer_activation": None, "last_layer_batchnorm": False, "last_layer_dropout": None},
+            "decoder": {"layers": [4, 8], "activation": ["leaky_relu", "leaky_relu"], "batchnorm": [False, False], "dropout": [0, 0],
+                        "last_layer_activation": None, "last_layer_batchnorm": False, "last_layer_dropout": None}}
+    runs = []
+    for kind in ("deep_tica", "ae"):
+        for bs in (256, 4096):
+            cfg = {"dimension": 2, "lag_time": 5, "features_normalization": "mean_std", "tica_regularization": 1e-6, "architecture": arch,
+                   "training": {"general": {"num_tries": 1, "seed": 42, "lengths": [0.8, 0.2], "batch_size": bs, "max_epochs": epochs, "shuffle": True,
+                                            "random_split": True, "check_val_every_n_epoch": 1, "save_check_every_n_epoch": 1},
+                                "early_stopping": {"patience": 100000, "min_delta": 0.0}, "optimizer": {"name": "Adam", "kwargs": {"lr": 1e-3, "weight_decay": 0}},
+                                "lr_scheduler": None, "lr_scheduler_config": None, "save_loss": False, "plot_loss": False, "model_to_save": "last"}}
+            with tempfile.TemporaryDirectory() as out, contextlib.redirect_stdout(sys.stderr):   # (stdout carries the one JSON line)
+                calc = cv_calculators_map[kind](cfg, out)
+                calc.set_training_matrix(X.copy(), names)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ok = calc.train()
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            steps = epochs * (int((n - (5 if kind == "deep_tica" else 0)) * 0.8) // bs)
+            runs.append({"cv": kind, "batch": bs, "epochs": epochs, "ok": bool(ok), "seconds": dt, "ms_per_epoch": dt / epochs * 1e3,
+                         "us_per_training_step_all_inclusive": dt / max(steps, 1) * 1e6, "value": steps * bs / dt, "unit": "frames/s"})
+    return {"workload": f"CVCalculator.train() wall clock, {n}x{F} f32 synthetic AR(1) features, encoder [16, 8], dimension 2, lag 5, random split + shuffled "
+                        f"loader, Adam 1e-3, {epochs} epochs with validation, one try", "runs": runs}
+
+
 def run_ref_small(a, steps, cpu_seconds):
     """Deep-TICA on the reference's OWN network sizes (cv_calculator.py:2569-2590): 54-16-8-2 (its test configuration,
     tests/data/input/train_colvars + test_train_colvars.py) and F-15-15-2 (tools/train_colvars/default_config.yml:45-55 `layers:
@@ -765,6 +810,8 @@ def main():
                     out["c2"]["cpu_baseline"] = c2["cpu_baseline"]
             if a.ref_small_steps > 0:
                 out["ref_small"] = run_ref_small(a, a.ref_small_steps, 0.0 if a.no_cpu_baseline else 3.0)
+            if a.fit_epochs > 0:
+                out["calculator_fit"] = run_calculator_fit(a.fit_epochs)
         print(json.dumps(out))
     if step_comm is not None:
         step_comm.close()   # the library's communicator goes before the process group that bootstrapped it

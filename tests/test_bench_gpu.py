@@ -89,7 +89,7 @@ def test_bench_single_gpu_line_carries_every_block():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "300000", "--batch", "4096", "--steps", "70", "--warmup", "3",
             "--cpu-seconds", "1", "--large-batch", "65516", "--large-steps", "3", "--other-mode-steps", "4", "--shuffled-steps", "40",
-            "--c2-steps", "420", "--ref-small-steps", "12"]
+            "--c2-steps", "420", "--ref-small-steps", "12", "--fit-epochs", "2"]
     p = subprocess.run(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -113,6 +113,9 @@ def test_bench_single_gpu_line_carries_every_block():
     assert c2["roofline"]["samples"] > 0
     rs = line["ref_small"]["runs"]
     assert len(rs) == 4 and all(x["fused_small_network_path"] and x["value"] > 0 for x in rs)
+    fits = line["calculator_fit"]["runs"]
+    assert [(x["cv"], x["batch"]) for x in fits] == [("deep_tica", 256), ("deep_tica", 4096), ("ae", 256), ("ae", 4096)]
+    assert all(x["ok"] and x["epochs"] == 2 and x["seconds"] > 0 for x in fits)
 
 
 @pytest.mark.parametrize("native", [False, True])
@@ -125,7 +128,7 @@ def test_bench_collective_path_on_real_rccl_world1(native):
     env["DCV_FORCE_DIST"] = "1"
     env["MASTER_PORT"] = str(_free_port())
     args = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--frames", "300000", "--batch", "4096", "--steps", "12", "--warmup", "3",
-            "--no-cpu-baseline", "--large-batch", "0", "--other-mode-steps", "0", "--shuffled-steps", "6", "--c2-steps", "0", "--ref-small-steps", "0"]
+            "--no-cpu-baseline", "--large-batch", "0", "--other-mode-steps", "0", "--shuffled-steps", "6", "--c2-steps", "0", "--ref-small-steps", "0", "--fit-epochs", "0"]
     if native:
         args.append("--native-rccl")
     p = subprocess.run(args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)

@@ -10,7 +10,7 @@ PARTS="${*:-tests timeline bench8k benchL c2 c3 c5 small lines}"
 cd $GRAFT_REPO_ROOT
 RC=0
 has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
-COMMON="--no-cpu-baseline --other-mode-steps 0 --shuffled-steps 0 --c2-steps 0 --ref-small-steps 0"
+COMMON="--no-cpu-baseline --other-mode-steps 0 --shuffled-steps 0 --c2-steps 0 --ref-small-steps 0 --fit-epochs 0"
 if has tests; then
   echo "--- tests $(date -u +%T)"
   python -m pytest tests -m gpu -q > gpurun_out/t_${TAG}_final.log 2>&1; tail -2 gpurun_out/t_${TAG}_final.log; grep -E "^FAILED|^ERROR" gpurun_out/t_${TAG}_final.log | head
@@ -19,15 +19,15 @@ fi
 if has timeline; then
   echo "--- step timelines $(date -u +%T)"
   BENCH_ARGS="--batch 8192 --steps 400 --warmup 50 --large-batch 0 --frames 2000000 $COMMON" bash tools/prof_small.sh ${TAG}_timeline | tail -9
-  BENCH_ARGS="--steps 20 --warmup 5 --large-batch 0 --frames 4000000 --no-cpu-baseline --other-mode-steps 0 --shuffled-steps 300 --c2-steps 0 --ref-small-steps 0" bash tools/prof_small.sh ${TAG}_shuffled | tail -9
+  BENCH_ARGS="--steps 20 --warmup 5 --large-batch 0 --frames 4000000 --no-cpu-baseline --other-mode-steps 0 --shuffled-steps 300 --c2-steps 0 --ref-small-steps 0 --fit-epochs 0" bash tools/prof_small.sh ${TAG}_shuffled | tail -9
 fi
 if has bench8k; then
   echo "--- bench8k passes $(date -u +%T)"
   PMC_CMDLINE="bench.py --steps 100 --warmup 20 --large-batch 0 --frames 2000000 $COMMON" \
     bash tools/prof_cmd.sh ${TAG}_bench8k bench.py --steps 800 --warmup 50 --large-batch 0 --frames 5000000 $COMMON | grep -E "exit"; [ ${PIPESTATUS[0]} -ne 0 ] && RC=1
   echo "--- shuffled passes $(date -u +%T)"
-  PMC_CMDLINE="bench.py --steps 5 --warmup 5 --large-batch 0 --frames 2000000 --no-cpu-baseline --other-mode-steps 0 --shuffled-steps 100 --c2-steps 0 --ref-small-steps 0" \
-    bash tools/prof_cmd.sh ${TAG}_shuffled8k bench.py --steps 5 --warmup 5 --large-batch 0 --frames 4000000 --no-cpu-baseline --other-mode-steps 0 --shuffled-steps 600 --c2-steps 0 --ref-small-steps 0 | grep -E "exit"; [ ${PIPESTATUS[0]} -ne 0 ] && RC=1
+  PMC_CMDLINE="bench.py --steps 5 --warmup 5 --large-batch 0 --frames 2000000 --no-cpu-baseline --other-mode-steps 0 --shuffled-steps 100 --c2-steps 0 --ref-small-steps 0 --fit-epochs 0" \
+    bash tools/prof_cmd.sh ${TAG}_shuffled8k bench.py --steps 5 --warmup 5 --large-batch 0 --frames 4000000 --no-cpu-baseline --other-mode-steps 0 --shuffled-steps 600 --c2-steps 0 --ref-small-steps 0 --fit-epochs 0 | grep -E "exit"; [ ${PIPESTATUS[0]} -ne 0 ] && RC=1
 fi
 if has benchL; then
   echo "--- benchL passes $(date -u +%T)"

@@ -304,3 +304,36 @@ def test_training_steps_in_one_call_equal_step_by_step(model, dims, batch, gathe
     a.train_step(Xd, **kw)
     b.train_step(Xd, **kw)
     assert torch.equal(a.params_view(), b.params_view())
+
+
+def test_epoch_entry_points_edge_cases():
+    """dcv_mlp_train_steps / dcv_mlp_eval_steps at the edges: zero and one batch, an engine with dropout (no fused kernels: the
+    validation pass steps batch by batch behind the same call, evaluation uses no masks), argument checks of the host wrapper."""
+    from deep_cartograph_amd import hip
+    from deep_cartograph_amd._lib import DcvError
+
+    dims, batch, lag = [54, 16, 8, 2], 64, 2
+    Xn, _, _ = normalized(ar_features(batch * 5 + 30, 54, 13))
+    Xd = torch.from_numpy(Xn).cuda()
+    for drops in (None, [0.25, 0.0, 0.0]):
+        torch.manual_seed(3)
+        eng = hip.Mlp("deep_tica", dims, ["tanh", "tanh", None], max_batch=batch, lag=lag, tica_reg=1e-6, dropout=drops, seed=5)
+        push_params(eng, [torch.nn.Linear(dims[i], dims[i + 1]) for i in range(3)])
+        eng.reset_log(16)
+        eng.train_steps(Xd, batch, 0, row0=0)
+        eng.eval_steps(Xd, batch, 0, row0=0)
+        assert len(eng.read_log()) == 0
+        eng.eval_steps(Xd, batch, 1, row0=4)            # one batch: the single step
+        eng.eval_step(Xd, row0=4, batch=batch)
+        eng.eval_steps(Xd, batch, 3, row0=4)
+        for j in range(3):
+            eng.eval_step(Xd, row0=4 + j * batch, batch=batch)
+        rec = eng.read_log()
+        assert rec.shape[0] == 8 and np.array_equal(rec[0], rec[1]) and np.array_equal(rec[2:5], rec[5:8])
+        assert eng.last_path() == (0 if drops else 2)
+        eng.train_steps(Xd, batch, 2, row0=0)
+        assert len(eng.read_log()) == 10 and np.isfinite(eng.read_log()).all()
+        with pytest.raises(DcvError):
+            eng.eval_steps(Xd, batch, 50, row0=0)       # rows beyond the matrix
+        with pytest.raises(DcvError):
+            eng.train_steps(Xd, batch, 3, idx=torch.arange(2 * batch).cuda())   # too few indices

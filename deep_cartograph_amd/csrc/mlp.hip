@@ -2521,7 +2521,7 @@ extern "C" int dcv_mlp_eval_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, con
         if (nb > 1 && !m->any_drop && !m->any_bn && !prof_on(m, 0)) {   // (a profiled run samples single steps)
             g_launch_ev = LaunchEvents{};
             if (m->desc.model == DCV_MODEL_AE && !(m->snet_tried && m->snet == nullptr)) {
-                const int tr = snet_ae_tile_rows(m);
+                const int tr = snet_ae_tile_rows(m, batch);
                 const int64_t per = cdiv((int64_t)batch, tr > 0 ? tr : 16);   // workgroups per batch
                 while (nb > 1 && per * nb > kEvalWorkgroupsPerLaunch) --nb;
                 if (nb > 1) rc = snet_ae_step(m, Xn_d, ld, RowMap{idx_j, row_j, 0, 0}, batch, batch, 0, nullptr, s, true, nb);

@@ -116,7 +116,7 @@ constexpr int64_t kEvalWorkgroupsPerLaunch = 4096;
 // R rows of this rank, `batch` = the GLOBAL batch (loss scale 2 / (batch * F)); write_log = false: the caller logs (after an all-reduce)
 int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, int64_t R, int64_t batch, int train, ReduceArgsView* ra,
                  hipStream_t s, bool write_log = true, int nb = 1);   // nb > 1: that many evaluation batches of R rows in one launch
-int snet_ae_tile_rows(dcv_mlp* m);   // rows per workgroup of the fused step (builds the plan on first use); 0: not applicable
+int snet_ae_tile_rows(dcv_mlp* m, int64_t R = 0);   // rows per workgroup of the fused kernel for batches of R rows (builds the plan on first use); 0: not applicable
 void snet_free(dcv_mlp* m);
 // the weight image both fused small-network plans stage from (snet.hip); repack: after the parameters were written by anyone
 // but the optimiser (dcv_mlp_set_params)

@@ -361,9 +361,9 @@ __global__ __launch_bounds__(kSnetThreads) void snet_ae_kernel(SnetArgs a) {
 }
 
 struct SnetPlan {
-    int TR;
-    size_t lds_bytes;
-    SnetArgs base;       // layer table and LDS map
+    int tr_max;          // largest tile (32 or 16 rows) whose activation map fits in LDS behind the weight images; 16 always fits when 32 does
+    int fl;              // LDS floats of the weight images
+    SnetArgs base;       // layer table (the activation map is laid out per launch: it depends on the tile rows)
     float* part;         // gradient partials
     int64_t part_floats; // capacity
     int64_t per_wg;      // floats of one workgroup's partials over all layers (dense: sum out * in + out)
@@ -374,6 +374,37 @@ struct SnetPlan {
     unsigned* ev_ticket; // ... and one ticket per batch + the one that moves the log counter (zero between launches)
     int64_t ev_ticket_n;
 };
+
+// Activation map of a TR-row tile behind the weight images (H_0 .. H_L, the reduction scratch); returns the LDS bytes, 0 when
+// the tile does not fit
+static size_t snet_ae_map(SnetArgs& a, int L, int fl, int TR) {
+    int f = fl;
+    for (int l = 0; l <= L; ++l) {
+        const int P = l == 0 ? a.l[0].pin : a.l[l - 1].pout;
+        if (l > 0 && l < L && a.l[l].pin != P) return 0;   // (always equal: both pad the same width)
+        a.ps[l] = P + 4;
+        a.lh[l] = f;
+        f += TR * (P + 4);
+    }
+    f = (f + 3) / 4 * 4;
+    a.lred = f;
+    f += 2 * kSnetThreads;   // kSnetThreads doubles
+    return (size_t)f * sizeof(float) <= (size_t)160 * 1024 ? (size_t)f * sizeof(float) : 0;
+}
+// Rows per workgroup of a launch over nb batches of R rows.  16-row tiles shorten the latency chain of a workgroup (54-16-8-2
+// autoencoder at batch 256: 32.4 -> 30.1 us per training step, A/B on one box) as long as their twice-as-many gradient partials
+// stay cheap -- one round of the chip, <= 4 MB for the reduction to read; at 4096 rows of the C2 network (21 MB of partials)
+// they gain nothing.  The choice depends on the rows of ONE batch only: a batched validation pass tiles its
+// batches as the single steps would, so its records stay bit-equal to theirs.
+static int snet_ae_pick_tr(const SnetPlan* pl, int64_t R) {
+    static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();   // 16 | 32: force the rows per workgroup
+    if ((tr_env == 16 || tr_env == 32) && tr_env <= pl->tr_max) return tr_env;
+    if (pl->tr_max == 32) {
+        const int64_t wg16 = cdiv(R, 16);
+        if (wg16 <= 256 && wg16 * pl->per_wg * (int64_t)sizeof(float) <= (4ll << 20)) return 16;
+    }
+    return pl->tr_max;
+}
 
 // Builds the plan once per engine.  Not applicable (returns false): wide layers, dropout, a network that does not fit
 // in LDS with at least 16-row tiles.
@@ -399,49 +430,40 @@ static bool snet_build(dcv_mlp* m) {
     }
     a.stage_tab = pl->stage_tab;
     a.stage_n = (int)tab.size();
-    const size_t lds_max = 160 * 1024;
-    static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();   // 16 | 32: force the rows per workgroup
+    pl->fl = fl;
+    pl->tr_max = 0;
     for (int TR : {32, 16}) {
-        if (tr_env != 0 && tr_env != TR) continue;
-        int f = fl;
-        for (int l = 0; l <= m->L; ++l) {
-            const int P = l == 0 ? a.l[0].pin : a.l[l - 1].pout;
-            if (l > 0 && l < m->L && a.l[l].pin != P) { f = 1 << 30; break; }   // (always equal: both pad the same width)
-            a.ps[l] = P + 4;
-            a.lh[l] = f;
-            f += TR * (P + 4);
+        SnetArgs tmp = a;
+        if (snet_ae_map(tmp, m->L, fl, TR) != 0) {
+            pl->tr_max = TR;
+            break;
         }
-        f = (f + 3) / 4 * 4;
-        a.lred = f;
-        f += 2 * kSnetThreads;   // kSnetThreads doubles
-        if ((size_t)f * sizeof(float) <= lds_max) {
-            pl->TR = TR;
-            pl->lds_bytes = (size_t)f * sizeof(float);
-            pl->part = nullptr;
-            pl->part_floats = 0;
-            pl->stamps = nullptr;
-            pl->ev_sse = nullptr;
-            pl->ev_sse_n = 0;
-            pl->ev_ticket = nullptr;
-            pl->ev_ticket_n = 0;
-            // batched validation passes: partials and tickets for the bounds of dcv_mlp_eval_steps (33 KB); without them the
-            // passes go batch by batch
-            if (hipMalloc(reinterpret_cast<void**>(&pl->ev_sse), (size_t)kEvalWorkgroupsPerLaunch * sizeof(double)) == hipSuccess &&
-                hipMalloc(reinterpret_cast<void**>(&pl->ev_ticket), (size_t)(kEvalBatchesPerLaunch + 1) * sizeof(unsigned)) == hipSuccess &&
-                hipMemset(pl->ev_ticket, 0, (size_t)(kEvalBatchesPerLaunch + 1) * sizeof(unsigned)) == hipSuccess) {
-                pl->ev_sse_n = kEvalWorkgroupsPerLaunch;
-                pl->ev_ticket_n = kEvalBatchesPerLaunch + 1;
-            } else {
-                (void)hipGetLastError();
-            }
-            {
-                const char* e = getenv("DCV_SNET_STAMPS");
-                if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void**>(&pl->stamps), 64 * sizeof(unsigned long long)) == hipSuccess)
-                    (void)hipMemset(pl->stamps, 0, 64 * sizeof(unsigned long long));
-            }
-            m->snet = pl;
-            return true;
+    }
+    if (pl->tr_max != 0) {
+        pl->part = nullptr;
+        pl->part_floats = 0;
+        pl->stamps = nullptr;
+        pl->ev_sse = nullptr;
+        pl->ev_sse_n = 0;
+        pl->ev_ticket = nullptr;
+        pl->ev_ticket_n = 0;
+        // batched validation passes: partials and tickets for the bounds of dcv_mlp_eval_steps (33 KB); without them the
+        // passes go batch by batch
+        if (hipMalloc(reinterpret_cast<void**>(&pl->ev_sse), (size_t)kEvalWorkgroupsPerLaunch * sizeof(double)) == hipSuccess &&
+            hipMalloc(reinterpret_cast<void**>(&pl->ev_ticket), (size_t)(kEvalBatchesPerLaunch + 1) * sizeof(unsigned)) == hipSuccess &&
+            hipMemset(pl->ev_ticket, 0, (size_t)(kEvalBatchesPerLaunch + 1) * sizeof(unsigned)) == hipSuccess) {
+            pl->ev_sse_n = kEvalWorkgroupsPerLaunch;
+            pl->ev_ticket_n = kEvalBatchesPerLaunch + 1;
+        } else {
+            (void)hipGetLastError();
         }
+        {
+            const char* e = getenv("DCV_SNET_STAMPS");
+            if (e && e[0] == '1' && hipMalloc(reinterpret_cast<void**>(&pl->stamps), 64 * sizeof(unsigned long long)) == hipSuccess)
+                (void)hipMemset(pl->stamps, 0, 64 * sizeof(unsigned long long));
+        }
+        m->snet = pl;
+        return true;
     }
     (void)hipFree(pl->stage_tab);
     delete pl;
@@ -518,8 +540,9 @@ void snet_free(dcv_mlp* m) {
     m->snet = nullptr;
 }
 
-// Rows per workgroup of the fused autoencoder step (the plan is built on first use); 0: the fused form does not apply.
-int snet_ae_tile_rows(dcv_mlp* m) {
+// Rows per workgroup the fused autoencoder kernel takes for batches of R rows (R = 0: its largest tile); the plan is built on
+// first use; 0: the fused form does not apply.
+int snet_ae_tile_rows(dcv_mlp* m, int64_t R) {
     if (m->snet == nullptr) {
         if (m->snet_tried || !snet_build(m)) {
             m->snet_tried = true;
@@ -527,7 +550,8 @@ int snet_ae_tile_rows(dcv_mlp* m) {
         }
         m->snet_tried = true;
     }
-    return static_cast<SnetPlan*>(m->snet)->TR;
+    const SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
+    return R > 0 ? snet_ae_pick_tr(pl, R) : pl->tr_max;
 }
 
 // One fused step of the autoencoder over `R` rows (train != 0: gradient partials are left for the reduction, whose
@@ -540,7 +564,8 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     static const int64_t kMaxPartBytes = 96ll << 20;
     if (snet_ae_tile_rows(m) == 0) return 1;
     SnetPlan* pl = static_cast<SnetPlan*>(m->snet);
-    const int64_t wgpb = cdiv(R, pl->TR);
+    const int TR = snet_ae_pick_tr(pl, R);
+    const int64_t wgpb = cdiv(R, TR);
     if (wgpb > m->spart_blocks || wgpb * pl->per_wg * (int64_t)sizeof(float) > kMaxPartBytes || wgpb > 512) return 1;   // large batches: the tiled products are the better engine
     if (nb < 1 || (nb > 1 && (train || !write_log))) return 1;
     const int64_t nwg = wgpb * nb;
@@ -557,6 +582,8 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
         pl->part_floats = part_need;
     }
     SnetArgs a = pl->base;
+    const size_t lds_bytes = snet_ae_map(a, m->L, pl->fl, TR);
+    if (lds_bytes == 0) return 1;
     int64_t off = 0;
     for (int l = 0; l < m->L; ++l) {
         SnetLayer& y = a.l[l];
@@ -595,7 +622,7 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
     a.stamps = pl->stamps;
     auto launch = [&](auto kern) -> int {
         static int attr_state[2] = {0, 0};   // 0 unknown, 1 set, -1 refused by the runtime (the fused form is then off)
-        const int slot = pl->TR == 32 ? 0 : 1;
+        const int slot = TR == 32 ? 0 : 1;
         if (attr_state[slot] == 0) {
             const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) (void)hipGetLastError();
@@ -606,14 +633,14 @@ int snet_ae_step(dcv_mlp* m, const float* Xn_d, int64_t ld, const RowMap& rm, in
             const LaunchEvents ev = g_launch_ev;
             g_launch_ev = LaunchEvents{};
             g_launch_taken = ev.start;
-            hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), (uint32_t)pl->lds_bytes, s, ev.start, ev.stop, 0u, a);
+            hipExtLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), (uint32_t)lds_bytes, s, ev.start, ev.stop, 0u, a);
         } else {
-            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), pl->lds_bytes, s, a);
+            hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(kSnetThreads), lds_bytes, s, a);
         }
         DCV_CHECK_LAUNCH();
         return DCV_OK;
     };
-    return pl->TR == 32 ? launch(snet_ae_kernel<32>) : launch(snet_ae_kernel<16>);
+    return TR == 32 ? launch(snet_ae_kernel<32>) : launch(snet_ae_kernel<16>);
 }
 
 }  // namespace dcv

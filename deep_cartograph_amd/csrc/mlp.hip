@@ -2527,7 +2527,7 @@ extern "C" int dcv_mlp_eval_steps(dcv_mlp* m, const float* Xn_d, int64_t ld, con
                 if (nb > 1) rc = snet_ae_step(m, Xn_d, ld, RowMap{idx_j, row_j, 0, 0}, batch, batch, 0, nullptr, s, true, nb);
                 if (rc == DCV_OK) m->last_path = 1;
             } else if (m->desc.model == DCV_MODEL_DEEPTICA && !(m->snet_dt_tried && m->snet_dt == nullptr)) {
-                const int64_t per = cdiv((int64_t)batch, 16);
+                const int64_t per = cdiv((int64_t)batch, 8);   // (an upper bound of the workgroups per batch: tiles of >= 8 pairs)
                 while (nb > 1 && per * nb > kEvalWorkgroupsPerLaunch) --nb;
                 if (nb > 1) rc = snet_dt_forward(m, Xn_d, ld, idx_j, row_j, batch, 2, false, s, nb);
                 if (rc == DCV_OK) m->last_path = 2;

@@ -606,6 +606,12 @@ static int snet_dt_map(SnetDtArgs& a, int fl, int TR) {
 static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
     static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();
     int best = 0;
+    // 16-row tiles (8 pairs per workgroup) for small batches: opt-in experiment (DCV_SNET_DT16=1)
+    static const bool dt16 = [] { const char* e = getenv("DCV_SNET_DT16"); return e && e[0] == '1'; }();
+    if (tr_env == 16 || (tr_env == 0 && dt16 && cdiv(B, 8) <= 256 && cdiv(B, 8) * pl->per_wg * (int64_t)sizeof(float) <= (4ll << 20))) {
+        SnetDtArgs tmp = pl->base;
+        if ((size_t)snet_dt_map(tmp, pl->fl, 16) * sizeof(float) <= kSnetDtLdsMax) return 16;
+    }
     for (int TR : {32, 64, 128}) {
         SnetDtArgs tmp = pl->base;
         if ((size_t)snet_dt_map(tmp, pl->fl, TR) * sizeof(float) > kSnetDtLdsMax) break;
@@ -765,6 +771,7 @@ int snet_dt_forward(dcv_mlp* m, const float* Xn_d, int64_t ld, const int64_t* id
     pl->last_wg = nb > 1 ? -1 : nwg;   // (no backward behind a batched evaluation)
     pl->last_tr = TR;
     switch (TR) {
+        case 16: return snet_dt_launch(snet_dt_fwd_kernel<16>, 3, lds_bytes, a, nwg, s);
         case 32: return snet_dt_launch(snet_dt_fwd_kernel<32>, 0, lds_bytes, a, nwg, s);
         case 64: return snet_dt_launch(snet_dt_fwd_kernel<64>, 1, lds_bytes, a, nwg, s);
         default: return snet_dt_launch(snet_dt_fwd_kernel<128>, 2, lds_bytes, a, nwg, s);
@@ -818,6 +825,7 @@ int snet_dt_backward(dcv_mlp* m, int32_t batch, int64_t global_batch, bool head,
     a.fused = FusedHead{0, 0.0, 0.0, nullptr, nullptr, nullptr, 0, 0};
     if (head) a.fused = FusedHead{1, (double)global_batch, m->desc.tica_reg, nullptr, m->log, m->log_count, m->log_cap, m->log_width};
     switch (TR) {
+        case 16: return snet_dt_launch(snet_dt_bwd_kernel<16>, 7, lds_bytes, a, nwg, s);
         case 32: return snet_dt_launch(snet_dt_bwd_kernel<32>, 4, lds_bytes, a, nwg, s);
         case 64: return snet_dt_launch(snet_dt_bwd_kernel<64>, 5, lds_bytes, a, nwg, s);
         default: return snet_dt_launch(snet_dt_bwd_kernel<128>, 6, lds_bytes, a, nwg, s);

@@ -72,7 +72,7 @@ union TicaWaveLdsAny {
     TicaWaveLds<3> h3;
     TicaWaveLds<4> h4;
 };
-// TR rows per workgroup = TR / 2 pairs (32, 64 or 128: larger tiles mean fewer statistics / gradient partials for the
+// TR rows per workgroup = TR / 2 pairs (16 for small batches, 32, 64 or 128: larger tiles mean fewer statistics / gradient partials for the
 // ticketed sums and the reduction launch behind; the work of a tile is latency, not arithmetic, at these widths)
 template <int TR>
 __global__ __launch_bounds__(kSnetThreads) void snet_dt_fwd_kernel(SnetDtArgs a) {
@@ -606,9 +606,12 @@ static int snet_dt_map(SnetDtArgs& a, int fl, int TR) {
 static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
     static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();
     int best = 0;
-    // 16-row tiles (8 pairs per workgroup) for small batches: opt-in experiment (DCV_SNET_DT16=1)
-    static const bool dt16 = [] { const char* e = getenv("DCV_SNET_DT16"); return e && e[0] == '1'; }();
-    if (tr_env == 16 || (tr_env == 0 && dt16 && cdiv(B, 8) <= 256 && cdiv(B, 8) * pl->per_wg * (int64_t)sizeof(float) <= (4ll << 20))) {
+    // 16-row tiles (8 pairs per workgroup) up to 1024 pairs: a shorter latency chain per workgroup while the twice-as-many
+    // partials stay cheap.  A/B on one box, 54-16-8-2, contiguous batches (tools/dbg/dt_tr_probe.py): 24.2 -> 23.2 us per step
+    // at 64 pairs, 24.7 -> 23.7 at 128, 25.5 -> 23.9 at 256, 25.4 -> 24.6 at 512, 26.1 -> 24.7 at 1024, and 26.1 -> 26.8
+    // (slower) at 2048; the gathered batch of 128 of bench.py's ref_small block: 29.1 -> 27.2.  DCV_SNET_DT16=0 turns them off.
+    static const bool dt16 = [] { const char* e = getenv("DCV_SNET_DT16"); return !(e && e[0] == '0'); }();
+    if (tr_env == 16 || (tr_env == 0 && dt16 && cdiv(B, 8) <= 128 && cdiv(B, 8) * pl->per_wg * (int64_t)sizeof(float) <= (4ll << 20))) {
         SnetDtArgs tmp = pl->base;
         if ((size_t)snet_dt_map(tmp, pl->fl, 16) * sizeof(float) <= kSnetDtLdsMax) return 16;
     }

@@ -145,7 +145,7 @@ def test_handoff_isa_order(tmp_path):
             assert inv and wait_after_inv and barrier_after, f"{name}: acquire / wait / barrier order behind the ticket is wrong"
             ticketed[name] = ticketed.get(name, 0) + 1
     names = " ".join(ticketed)
-    assert all(v == 1 and ticketed.get(k, 0) >= 1 for k, v in elections.items()) and len(elections) == 5, elections   # AE TR 32 / 16, Deep-TICA TR 32 / 64 / 128
+    assert all(v == 1 and ticketed.get(k, 0) >= 1 for k, v in elections.items()) and len(elections) == 6, elections   # AE TR 32 / 16, Deep-TICA TR 16 / 32 / 64 / 128
     assert "ae_sse_kernel" in names
     for d in (1, 2, 3, 4):
         assert f"tica_stats_rows_kernelILi{d}E" in names

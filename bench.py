@@ -803,15 +803,29 @@ def main():
             del X, Xn
             torch.cuda.empty_cache()
             cpu_s = 0.0 if a.no_cpu_baseline else min(a.cpu_seconds, 8.0)
-            if a.c2_steps > 0:
+            def block(name, fn):   # a block that fails is reported as such: the headline above is measured and must be printed
+                try:
+                    out[name] = fn()
+                except Exception as e:   # noqa: BLE001
+                    import traceback
+
+                    traceback.print_exc(file=sys.stderr)
+                    out[name] = {"error": f"{type(e).__name__}: {e}"}
+                torch.cuda.empty_cache()
+
+            def c2_block():
                 c2 = run_c2(a, a.c2_steps, 50, cpu_s)
-                out["c2"] = {k: c2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "loss_first", "loss_last", "roofline") if k in c2}
+                blk = {k: c2[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "loss_first", "loss_last", "roofline") if k in c2}
                 if "cpu_baseline" in c2:
-                    out["c2"]["cpu_baseline"] = c2["cpu_baseline"]
+                    blk["cpu_baseline"] = c2["cpu_baseline"]
+                return blk
+
+            if a.c2_steps > 0:
+                block("c2", c2_block)
             if a.ref_small_steps > 0:
-                out["ref_small"] = run_ref_small(a, a.ref_small_steps, 0.0 if a.no_cpu_baseline else 3.0)
+                block("ref_small", lambda: run_ref_small(a, a.ref_small_steps, 0.0 if a.no_cpu_baseline else 3.0))
             if a.fit_epochs > 0:
-                out["calculator_fit"] = run_calculator_fit(a.fit_epochs)
+                block("calculator_fit", lambda: run_calculator_fit(a.fit_epochs))
         print(json.dumps(out))
     if step_comm is not None:
         step_comm.close()   # the library's communicator goes before the process group that bootstrapped it

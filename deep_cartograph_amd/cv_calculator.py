@@ -1101,7 +1101,8 @@ class NonLinear(CVCalculator):
             do_val = (epoch + 1) % self.check_val_every_n_epoch == 0
             vb = self._batches(val_part, bs, dev) if do_val else []
             self.engine.reset_log(len(tb) + len(vb))
-            self._run_batches(Xn_train, tb, True, gb, per_step=sched.after_step if sched is not None else None)
+            # (a scheduler stepped per EPOCH -- lightning's default interval -- has nothing to do between the steps of an epoch)
+            self._run_batches(Xn_train, tb, True, gb, per_step=sched.after_step if sched is not None and sched.interval == "step" else None)
             self._run_batches(Xn_val, vb, False, gb)
             # While the device works through the epoch just enqueued: the NEXT epoch's permutation and index upload (a CPU
             # randperm of 10 M indices is ~0.1 s -- as long as the epoch itself).  The draws keep the reference's order (train

@@ -391,17 +391,17 @@ static size_t snet_ae_map(SnetArgs& a, int L, int fl, int TR) {
     f += 2 * kSnetThreads;   // kSnetThreads doubles
     return (size_t)f * sizeof(float) <= (size_t)160 * 1024 ? (size_t)f * sizeof(float) : 0;
 }
-// Rows per workgroup of a launch over nb batches of R rows.  16-row tiles shorten the latency chain of a workgroup (54-16-8-2
-// autoencoder at batch 256: 32.4 -> 30.1 us per training step, A/B on one box) as long as their twice-as-many gradient partials
-// stay cheap -- one round of the chip, <= 4 MB for the reduction to read; at 4096 rows of the C2 network (21 MB of partials)
-// they gain nothing.  The choice depends on the rows of ONE batch only: a batched validation pass tiles its
+// Rows per workgroup for batches of R rows.  16-row tiles shorten the latency chain of a workgroup; measured on one box
+// (tools/dbg/ae_tr_probe.py, contiguous batches, us per training step, 16 | 32 rows): 54-16-8-2 autoencoder 27.0 | 28.5 at batch
+// 128, 27.0 | 29.4 at 512, 28.2 | 29.8 at 2048, 30.8 | 30.3 at 4096; the C2 network 128-64-32-2: 31.1 | 35.7 at 128, 31.1 | 36.9
+// at 512, 33.1 | 37.3 at 2048 (21 MB of partials and still ahead), 37.4 | 37.9 at 4096.  So: 16 rows up to 2048 rows (128
+// workgroups), the larger tile beyond.  The choice depends on the rows of ONE batch only: a batched validation pass tiles its
 // batches as the single steps would, so its records stay bit-equal to theirs.
 static int snet_ae_pick_tr(const SnetPlan* pl, int64_t R) {
     static const int tr_env = [] { const char* e = getenv("DCV_SNET_TR"); return e ? atoi(e) : 0; }();   // 16 | 32: force the rows per workgroup
     if ((tr_env == 16 || tr_env == 32) && tr_env <= pl->tr_max) return tr_env;
     if (pl->tr_max == 32) {
-        const int64_t wg16 = cdiv(R, 16);
-        if (wg16 <= 256 && wg16 * pl->per_wg * (int64_t)sizeof(float) <= (4ll << 20)) return 16;
+        if (cdiv(R, 16) <= 128) return 16;
     }
     return pl->tr_max;
 }

@@ -611,7 +611,9 @@ static int snet_dt_pick_tr(const SnetDtPlan* pl, int64_t B) {
     // at 64 pairs, 24.7 -> 23.7 at 128, 25.5 -> 23.9 at 256, 25.4 -> 24.6 at 512, 26.1 -> 24.7 at 1024, and 26.1 -> 26.8
     // (slower) at 2048; the gathered batch of 128 of bench.py's ref_small block: 29.1 -> 27.2.  DCV_SNET_DT16=0 turns them off.
     static const bool dt16 = [] { const char* e = getenv("DCV_SNET_DT16"); return !(e && e[0] == '0'); }();
-    if (tr_env == 16 || (tr_env == 0 && dt16 && cdiv(B, 8) <= 128 && cdiv(B, 8) * pl->per_wg * (int64_t)sizeof(float) <= (4ll << 20))) {
+    // (128-64-32-4 on the same box, 16 | 32 rows: 25.8 | 28.0 at 128 pairs, 27.9 | 29.3 at 1024 -- 5.4 MB of partials and still ahead --
+    // 32.4 | 30.4 at 2048, 53 | 35 at 4096: two rounds of the chip)
+    if (tr_env == 16 || (tr_env == 0 && dt16 && cdiv(B, 8) <= 128)) {
         SnetDtArgs tmp = pl->base;
         if ((size_t)snet_dt_map(tmp, pl->fl, 16) * sizeof(float) <= kSnetDtLdsMax) return 16;
     }

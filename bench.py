@@ -88,6 +88,11 @@ def init_linears(dims, seed):
     return [(l.weight.detach().numpy().copy(), l.bias.detach().numpy().copy()) for l in lins]
 
 
+def settle_host():
+    """Behind a torch-CPU baseline: let its worker threads stop spinning before the next short GPU measurement is issued."""
+    time.sleep(0.5)
+
+
 def cpu_baseline(Xn_host, dims, acts, lag, batch, lr, seconds, linears):
     """The CPU restatement of the reference path (oracle: torch-CPU autograd + Adam, same
     architecture, batch and dtype) timed on this box's host cores on a bounded sample."""
@@ -489,6 +494,7 @@ def run_c2(a, steps, warmup, cpu_seconds):
                                       std.astype(np.float32))
         out["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{done} optimiser steps of the torch-CPU oracle (same autoencoder, f32, batches of {bs}) on the first {rows} frames, {dt:.1f} s"}
+        settle_host()
     eng.close()
     del X, Xn
     return out
@@ -552,7 +558,7 @@ def run_ref_small(a, steps, cpu_seconds):
     std = st["std"].copy()
     std[np.abs(std) < 1e-8] = 1.0
     hip.normalize(X, torch.from_numpy(st["mean"]).to(dev), torch.from_numpy(std).to(dev), out=X)
-    rows_out = []
+    rows_out, todo_cpu = [], []
     for hidden in ([16, 8], [15, 15]):
         dims = [F] + hidden + [2]
         acts = ["leaky_relu"] * (len(dims) - 2) + [None]
@@ -571,12 +577,18 @@ def run_ref_small(a, steps, cpu_seconds):
                                 "note": "whole step (every launch + gaps): algorithmic 12 * sum(in*out) * batch flop / step time; latency-bound by "
                                         "construction at these sizes -- reported for the record"}}
             fit.close()
-            if cpu_seconds > 0:
-                sample_rows = min(n, 40 * bs + lag)
-                v, done, dt = cpu_baseline(X[:sample_rows].cpu().numpy(), dims, acts, lag, bs, a.lr, cpu_seconds, linears)
-                rec["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                                       "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, contiguous batches of {bs} pairs), {dt:.1f} s"}
             rows_out.append(rec)
+            todo_cpu.append((rec, dims, acts, bs, linears))
+    # the CPU baselines AFTER every GPU measurement of the block: the worker threads of a 128-thread torch-CPU run keep spinning
+    # for a while behind it, and a 10 ms GPU measurement started right behind one read 10 x too long now and then
+    # (profiles/r04_bench_line_driver_form.json of 07:54: 296 us per step between two runs at 27 and 34)
+    if cpu_seconds > 0:
+        for rec, dims, acts, bs, linears in todo_cpu:
+            sample_rows = min(n, 40 * bs + lag)
+            v, done, dt = cpu_baseline(X[:sample_rows].cpu().numpy(), dims, acts, lag, bs, a.lr, cpu_seconds, linears)
+            rec["cpu_baseline"] = {"value": v, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                   "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, contiguous batches of {bs} pairs), {dt:.1f} s"}
+        settle_host()
     del X
     return {"workload": f"Deep-TICA fit on the reference's own network sizes, {n}x{F} f32 synthetic AR(1) features, lag {lag}, Adam lr {a.lr}, "
                         "random split + per-epoch permutation (the reference's default loader), training steps only",
@@ -798,6 +810,7 @@ def main():
                 "sample": f"{done} optimiser steps of the torch-CPU oracle (same MLP, f32, batches of {a.batch} pairs) on the first "
                           f"{sample_rows} frames, {dt:.1f} s",
             }
+            settle_host()
         if world == 1 and dist is None:
             # bounded runs of the other single-GPU configurations, carried by the same JSON line (the driver records one line)
             del X, Xn

@@ -1,3 +1,5 @@
+# Generic A/B over the small-network measurements for a 0 / 1 environment switch of the library.  Its last use, DCV_SNET_XFIRST
+# (input rows requested ahead of the weight-image copy), was an experiment that was not kept and not committed.
 # usage: ab_env.sh VAR  -- alternates VAR=0 / VAR=1 twice over the small-network measurements
 V=$1
 for rep in 1 2; do for x in 0 1; do

@@ -1,3 +1,4 @@
+# A/B script of an experiment that was NOT kept: DCV_OPT_PREFETCH exists only in commit 6cd40db (reverted by 58f0bcd).
 for rep in 1 2; do for pf in 0 1; do
 echo "== DCV_OPT_PREFETCH=$pf (rep $rep)"
 DCV_OPT_PREFETCH=$pf python bench.py --config ref_small --steps 600 --no-cpu-baseline 2>/dev/null | python -c "

@@ -154,11 +154,12 @@ def _same_clustering(a: torch.Tensor, b: torch.Tensor, k: int) -> bool:
 
 
 def kmeans_clustering(feature_matrix: np.ndarray, num_clusters: int, n_init: int,
-                      initial_centroids: Optional[np.ndarray] = None, comm: Optional[Comm] = None):
+                      initial_centroids: Optional[np.ndarray] = None, comm: Optional[Comm] = None, pts: Optional[_DevicePoints] = None):
     """KMeans(n_clusters, random_state=0, init='k-means++' | array, n_init).fit_predict on the
     GPU.  Returns (labels int32 NumPy of this rank's points, centres k x d float64)."""
     comm = comm or Comm()
-    pts = _DevicePoints(feature_matrix, comm)
+    if pts is None:   # (optimize_clustering hands in the resident points: one upload for the whole scan over k)
+        pts = _DevicePoints(feature_matrix, comm)
     rs = np.random.RandomState(0)
     if initial_centroids is not None:
         init = np.asarray(initial_centroids, dtype=np.float64) - pts.mean
@@ -178,7 +179,7 @@ def kmeans_clustering(feature_matrix: np.ndarray, num_clusters: int, n_init: int
     return labels.cpu().numpy(), centers + pts.mean
 
 
-def cluster_data(features: np.ndarray, settings: Dict, initial_centroids: np.ndarray = None) -> Tuple[np.ndarray, np.ndarray]:
+def cluster_data(features: np.ndarray, settings: Dict, initial_centroids: np.ndarray = None, pts: Optional[_DevicePoints] = None) -> Tuple[np.ndarray, np.ndarray]:
     """Cluster with the algorithm named in `settings` (defaults filled in place, as the reference
     does, statistics.py:134-142)."""
     settings["algorithm"] = settings.get("algorithm", "kmeans")
@@ -192,7 +193,7 @@ def cluster_data(features: np.ndarray, settings: Dict, initial_centroids: np.nda
     settings["cluster_selection_method"] = settings.get("cluster_selection_method", "eom")
     algo = settings["algorithm"]
     if algo == "kmeans":
-        return kmeans_clustering(features, settings["num_clusters"], settings["n_init"], initial_centroids)
+        return kmeans_clustering(features, settings["num_clusters"], settings["n_init"], initial_centroids, pts=pts)
     if algo == "hierarchical":
         from sklearn.cluster import AgglomerativeClustering
 
@@ -212,7 +213,7 @@ def cluster_data(features: np.ndarray, settings: Dict, initial_centroids: np.nda
 
 
 def clustering_scores(features: np.ndarray, labels: np.ndarray, comm: Optional[Comm] = None,
-                      silhouette_max_points: Optional[int] = None) -> Tuple[float, float, float]:
+                      silhouette_max_points: Optional[int] = None, P_dev: Optional[torch.Tensor] = None) -> Tuple[float, float, float]:
     """(Calinski-Harabasz, Davies-Bouldin, silhouette) of a labelling on the GPU, the definitions of
     sklearn.metrics the reference calls (statistics.py:73-75).  `features` / `labels` are this rank's
     block of frames.  CH and DB are two streaming passes (label sums -> means, then dispersions);
@@ -221,7 +222,7 @@ def clustering_scores(features: np.ndarray, labels: np.ndarray, comm: Optional[C
     query points against all points."""
     comm = comm or Comm()
     dev = _device()
-    P = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float64)).to(dev)
+    P = P_dev if P_dev is not None else torch.from_numpy(np.ascontiguousarray(features, dtype=np.float64)).to(dev)
     lab = torch.from_numpy(np.ascontiguousarray(labels, dtype=np.int32)).to(dev)
     d = P.shape[1]
     k = int(comm.max_(lab.max().reshape(1).to(torch.int64)).item()) + 1 if comm.active else int(lab.max().item()) + 1
@@ -285,11 +286,13 @@ def optimize_clustering(features: np.ndarray, settings: Dict):
         lo, hi = settings.get("search_interval", [2, 15])
         ks = list(range(lo, hi + 1))
         ch, db, si, results = [], [], [], []
+        # k-means: the points go to the GPU once for the whole scan (each k used to upload them twice: clustering, then scores)
+        pts = _DevicePoints(features, Comm()) if settings["algorithm"] == "kmeans" else None
         for N in ks:
             settings["num_clusters"] = N
-            labels, centroids = cluster_data(features, settings)
+            labels, centroids = cluster_data(features, settings, pts=pts)
             if settings["algorithm"] == "kmeans":   # scores on the GPU (same definitions: clustering_scores)
-                c_, d_, s_ = clustering_scores(features, labels, silhouette_max_points=settings.get("silhouette_max_points"))
+                c_, d_, s_ = clustering_scores(features, labels, silhouette_max_points=settings.get("silhouette_max_points"), P_dev=pts.P)
             else:
                 c_, d_, s_ = (calinski_harabasz_score(features, labels), davies_bouldin_score(features, labels),
                               silhouette_score(features, labels))
